@@ -1,0 +1,157 @@
+"""Shape configuration of the three hot-path stages.
+
+Defaults are the CosyVoice2 wiring of the reference
+(/root/reference/examples/tts_vc/cosyvoice2/conf/cosyvoice.yaml:17-102) and the
+Qwen2.5-0.5B backbone shape the reference reads from ``config.json``
+(/root/reference/cosyvoice/llm/llm.py:749-752).  ``tiny_*`` constructors give
+reduced shapes used by the CPU parity tests and the golden fixtures.
+"""
+from dataclasses import dataclass, field, replace
+from typing import Tuple
+
+
+@dataclass(frozen=True)
+class HiftConfig:
+    # /root/reference/cosyvoice/hifigan/generator.py:228-246 (ctor defaults = v1 22.05 kHz),
+    # cosyvoice2 yaml :82-102 (24 kHz, ups 8/5/3)
+    in_channels: int = 80
+    base_channels: int = 512
+    nb_harmonics: int = 8
+    sampling_rate: int = 24000
+    nsf_alpha: float = 0.1
+    nsf_sigma: float = 0.003
+    nsf_voiced_threshold: float = 10.0
+    upsample_rates: Tuple[int, ...] = (8, 5, 3)
+    upsample_kernel_sizes: Tuple[int, ...] = (16, 11, 7)
+    n_fft: int = 16
+    hop_len: int = 4
+    resblock_kernel_sizes: Tuple[int, ...] = (3, 7, 11)
+    resblock_dilation_sizes: Tuple[Tuple[int, ...], ...] = ((1, 3, 5), (1, 3, 5), (1, 3, 5))
+    source_resblock_kernel_sizes: Tuple[int, ...] = (7, 7, 11)
+    source_resblock_dilation_sizes: Tuple[Tuple[int, ...], ...] = ((1, 3, 5), (1, 3, 5), (1, 3, 5))
+    lrelu_slope: float = 0.1
+    audio_limit: float = 0.99
+    f0_cond_channels: int = 512
+
+    @property
+    def total_upsample(self) -> int:
+        u = 1
+        for r in self.upsample_rates:
+            u *= r
+        return u * self.hop_len
+
+    @staticmethod
+    def v2() -> "HiftConfig":
+        return HiftConfig()
+
+    @staticmethod
+    def v1() -> "HiftConfig":
+        # /root/reference/examples/tts_vc/cosyvoice/conf/cosyvoice.yaml:116-141
+        return HiftConfig(sampling_rate=22050, upsample_rates=(8, 8), upsample_kernel_sizes=(16, 16),
+                          source_resblock_kernel_sizes=(7, 11),
+                          source_resblock_dilation_sizes=((1, 3, 5), (1, 3, 5)))
+
+    @staticmethod
+    def tiny() -> "HiftConfig":
+        return HiftConfig(base_channels=128, upsample_rates=(4, 3), upsample_kernel_sizes=(8, 7),
+                          resblock_kernel_sizes=(3, 7), resblock_dilation_sizes=((1, 3), (1, 3)),
+                          source_resblock_kernel_sizes=(7, 11),
+                          source_resblock_dilation_sizes=((1, 3), (1, 3)), f0_cond_channels=64)
+
+
+@dataclass(frozen=True)
+class FlowConfig:
+    # CausalMaskedDiffWithXvec, /root/reference/cosyvoice/flow/flow.py:164-201 + yaml :35-80
+    input_size: int = 512
+    output_size: int = 80
+    spk_embed_dim: int = 192
+    vocab_size: int = 6561
+    input_frame_rate: int = 25
+    token_mel_ratio: int = 2
+    pre_lookahead_len: int = 3
+    # UpsampleConformerEncoder (transformer/upsample_encoder.py:100-235)
+    enc_dim: int = 512
+    enc_heads: int = 8
+    enc_linear_units: int = 2048
+    enc_blocks: int = 6
+    enc_up_blocks: int = 4
+    # ConditionalDecoder (flow/decoder.py:88-206), channels=[256]
+    est_in_channels: int = 320
+    est_channels: int = 256
+    est_n_blocks: int = 4
+    est_mid_blocks: int = 12
+    est_heads: int = 8
+    est_head_dim: int = 64
+    est_ff_mult: int = 4
+    # CFM (flow/flow_matching.py:22-36, yaml :59-67)
+    inference_cfg_rate: float = 0.7
+    n_timesteps: int = 10
+    noise_len: int = 50 * 300
+
+    @property
+    def est_time_dim(self) -> int:
+        return self.est_channels * 4
+
+    @property
+    def est_inner(self) -> int:
+        return self.est_heads * self.est_head_dim
+
+    @staticmethod
+    def full() -> "FlowConfig":
+        return FlowConfig()
+
+    @staticmethod
+    def tiny() -> "FlowConfig":
+        # enc_dim stays 512: the reference hard-codes 512 channels in PreLookaheadLayer / Upsample1D
+        # (transformer/upsample_encoder.py:207,223)
+        return FlowConfig(vocab_size=200, enc_linear_units=128, enc_blocks=1, enc_up_blocks=1,
+                          est_n_blocks=1, est_mid_blocks=2)
+
+
+@dataclass(frozen=True)
+class LlmConfig:
+    # Qwen2LM, /root/reference/cosyvoice/llm/llm.py:769-804; backbone shape = Qwen2.5-0.5B config.json
+    hidden_size: int = 896
+    num_layers: int = 24
+    num_heads: int = 14
+    num_kv_heads: int = 2
+    head_dim: int = 64
+    intermediate_size: int = 4864
+    vocab_size: int = 151936
+    rms_eps: float = 1e-6
+    rope_theta: float = 1000000.0
+    speech_token_size: int = 6561
+    tie_word_embeddings: bool = True
+
+    @property
+    def q_dim(self) -> int:
+        return self.num_heads * self.head_dim
+
+    @property
+    def kv_dim(self) -> int:
+        return self.num_kv_heads * self.head_dim
+
+    @property
+    def out_vocab(self) -> int:
+        return self.speech_token_size + 3
+
+    @staticmethod
+    def full() -> "LlmConfig":
+        return LlmConfig()
+
+    @staticmethod
+    def tiny() -> "LlmConfig":
+        return LlmConfig(hidden_size=256, num_layers=2, num_heads=4, num_kv_heads=2, head_dim=64,
+                         intermediate_size=512, vocab_size=512, speech_token_size=125)
+
+    def hf_config_dict(self) -> dict:
+        """The ``config.json`` the reference's Qwen2Encoder would read (llm.py:749-752)."""
+        return dict(hidden_size=self.hidden_size, num_hidden_layers=self.num_layers,
+                    num_attention_heads=self.num_heads, num_key_value_heads=self.num_kv_heads,
+                    intermediate_size=self.intermediate_size, vocab_size=self.vocab_size,
+                    rms_norm_eps=self.rms_eps, rope_theta=self.rope_theta, hidden_act="silu",
+                    max_position_embeddings=32768, tie_word_embeddings=self.tie_word_embeddings,
+                    attention_dropout=0.0, use_sliding_window=False, model_type="qwen2")
+
+
+__all__ = ["HiftConfig", "FlowConfig", "LlmConfig", "replace", "field"]

@@ -1,0 +1,282 @@
+"""Oracle for the flow-matching mel decoder (TEST INFRASTRUCTURE — see oracle/__init__.py).
+
+Functional restatement over a flat state dict with the reference's key names.
+"""
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from cosyvoice_amd.config import FlowConfig
+
+
+def _lin(sd, name, x):
+    return F.linear(x, sd[f"{name}.weight"], sd.get(f"{name}.bias"))
+
+
+def _ln(sd, name, x, eps):
+    return F.layer_norm(x, (x.shape[-1],), sd[f"{name}.weight"], sd[f"{name}.bias"], eps)
+
+
+# ------------------------------------------------------------------ masks (utils/mask.py)
+def make_pad_mask(lengths: torch.Tensor, max_len: int = 0) -> torch.Tensor:
+    # utils/mask.py:203-229
+    max_len = max_len if max_len > 0 else int(lengths.max().item())
+    rng = torch.arange(0, max_len, dtype=torch.int64)
+    return rng[None, :] >= lengths[:, None]
+
+
+def subsequent_chunk_mask(size: int, chunk_size: int) -> torch.Tensor:
+    # utils/mask.py:89-124 with num_left_chunks = -1: row i sees keys [0, (i//cs+1)*cs)
+    i = torch.arange(size)
+    ending = torch.clamp((i // chunk_size + 1) * chunk_size, max=size)
+    return torch.arange(size)[None, :] < ending[:, None]
+
+
+def chunk_masks(masks: torch.Tensor, size: int, static_chunk_size: int) -> torch.Tensor:
+    # add_optional_chunk_mask, utils/mask.py:127-200, inference branch (use_dynamic_chunk False)
+    if static_chunk_size > 0:
+        return masks & subsequent_chunk_mask(size, static_chunk_size)[None]
+    return masks
+
+
+# ------------------------------------------------------------------ encoder
+def rel_pos_table(d_model: int, size: int) -> torch.Tensor:
+    """EspnetRelPositionalEncoding.position_encoding(size): (1, 2*size-1, d) — embedding.py:220-294.
+    Row m encodes relative position (size-1-m)."""
+    pos = torch.arange(size - 1, -size, -1, dtype=torch.float32).unsqueeze(1)  # size-1 ... -(size-1)
+    div = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float32) * -(math.log(10000.0) / d_model))
+    pe = torch.zeros(2 * size - 1, d_model)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe.unsqueeze(0)
+
+
+def rel_shift(x: torch.Tensor) -> torch.Tensor:
+    # attention.py:225-247
+    b, h, t1, n = x.shape
+    zero_pad = torch.zeros((b, h, t1, 1), dtype=x.dtype)
+    x_padded = torch.cat([zero_pad, x], dim=-1).view(b, h, n + 1, t1)
+    return x_padded[:, :, 1:].view_as(x)[:, :, :, : n // 2 + 1]
+
+
+def rel_attention(sd, name, x, mask, pos_emb, heads):
+    """RelPositionMultiHeadedAttention.forward, attention.py:249-330 (no cache)."""
+    B, T, D = x.shape
+    dk = D // heads
+    q = _lin(sd, f"{name}.linear_q", x).view(B, T, heads, dk)
+    k = _lin(sd, f"{name}.linear_k", x).view(B, T, heads, dk).transpose(1, 2)
+    v = _lin(sd, f"{name}.linear_v", x).view(B, T, heads, dk).transpose(1, 2)
+    p = F.linear(pos_emb, sd[f"{name}.linear_pos.weight"]).view(1, -1, heads, dk).transpose(1, 2)
+    q_u = (q + sd[f"{name}.pos_bias_u"]).transpose(1, 2)
+    q_v = (q + sd[f"{name}.pos_bias_v"]).transpose(1, 2)
+    ac = torch.matmul(q_u, k.transpose(-2, -1))
+    bd = rel_shift(torch.matmul(q_v, p.transpose(-2, -1)))
+    scores = (ac + bd) / math.sqrt(dk)
+    m = mask.unsqueeze(1).eq(0)
+    scores = scores.masked_fill(m, -float("inf"))
+    attn = torch.softmax(scores, dim=-1).masked_fill(m, 0.0)
+    o = torch.matmul(attn, v).transpose(1, 2).contiguous().view(B, T, D)
+    return _lin(sd, f"{name}.linear_out", o)
+
+
+def conformer_layer(sd, name, x, mask, pos_emb, heads):
+    # encoder_layer.py:161-236 with no macaron, no cnn module, normalize_before=True
+    r = x
+    x = r + rel_attention(sd, f"{name}.self_attn", _ln(sd, f"{name}.norm_mha", x, 1e-12), mask, pos_emb, heads)
+    r = x
+    h = _ln(sd, f"{name}.norm_ff", x, 1e-12)
+    h = _lin(sd, f"{name}.feed_forward.w_2", F.silu(_lin(sd, f"{name}.feed_forward.w_1", h)))
+    return r + h
+
+
+def embed(sd, name, x, d_model):
+    # LinearNoSubsampling + EspnetRelPositionalEncoding.forward: subsampling.py:69-113, embedding.py:257-270
+    x = _ln(sd, f"{name}.out.1", _lin(sd, f"{name}.out.0", x), 1e-5)
+    return x * math.sqrt(d_model), rel_pos_table(d_model, x.shape[1])
+
+
+def encoder_forward(sd, cfg: FlowConfig, xs: torch.Tensor, xs_lens: torch.Tensor, static_chunk_size: int = 0,
+                    prefix: str = "encoder."):
+    """UpsampleConformerEncoder.forward, upsample_encoder.py:237-304.  xs (B,N,512) -> (B,2N,512)."""
+    T = xs.shape[1]
+    masks = ~make_pad_mask(xs_lens, T).unsqueeze(1)
+    xs, pos_emb = embed(sd, f"{prefix}embed", xs, cfg.enc_dim)
+    cm = chunk_masks(masks, T, static_chunk_size)
+    # PreLookaheadLayer, upsample_encoder.py:81-96
+    o = xs.transpose(1, 2)
+    o = F.pad(o, (0, cfg.pre_lookahead_len))
+    o = F.leaky_relu(F.conv1d(o, sd[f"{prefix}pre_lookahead_layer.conv1.weight"], sd[f"{prefix}pre_lookahead_layer.conv1.bias"]))
+    o = F.pad(o, (2, 0))
+    o = F.conv1d(o, sd[f"{prefix}pre_lookahead_layer.conv2.weight"], sd[f"{prefix}pre_lookahead_layer.conv2.bias"])
+    xs = o.transpose(1, 2) + xs
+    for i in range(cfg.enc_blocks):
+        xs = conformer_layer(sd, f"{prefix}encoders.{i}", xs, cm, pos_emb, cfg.enc_heads)
+    # Upsample1D, upsample_encoder.py:59-63: nearest x2, left pad 4, conv k5
+    o = xs.transpose(1, 2)
+    o = F.interpolate(o, scale_factor=2.0, mode="nearest")
+    o = F.pad(o, (4, 0))
+    o = F.conv1d(o, sd[f"{prefix}up_layer.conv.weight"], sd[f"{prefix}up_layer.conv.bias"])
+    xs = o.transpose(1, 2)
+    xs_lens = xs_lens * 2
+    T = xs.shape[1]
+    masks = ~make_pad_mask(xs_lens, T).unsqueeze(1)
+    xs, pos_emb = embed(sd, f"{prefix}up_embed", xs, cfg.enc_dim)
+    cm = chunk_masks(masks, T, static_chunk_size * 2)
+    for i in range(cfg.enc_up_blocks):
+        xs = conformer_layer(sd, f"{prefix}up_encoders.{i}", xs, cm, pos_emb, cfg.enc_heads)
+    return _ln(sd, f"{prefix}after_norm", xs, 1e-5), masks
+
+
+# ------------------------------------------------------------------ estimator
+def sinusoidal_pos_emb(t: torch.Tensor, dim: int, scale: float = 1000.0) -> torch.Tensor:
+    # flow/components/decoder.py:12-27
+    half = dim // 2
+    e = math.log(10000) / (half - 1)
+    e = torch.exp(torch.arange(half, dtype=torch.float32) * -e)
+    e = scale * t.unsqueeze(1) * e.unsqueeze(0)
+    return torch.cat((e.sin(), e.cos()), dim=-1)
+
+
+def causal_block(sd, name, x, mask):
+    # CausalBlock1D, flow/decoder.py:36-49: causal conv k3 -> LayerNorm(C) -> Mish, masked in/out
+    h = F.conv1d(F.pad(x * mask, (2, 0)), sd[f"{name}.block.0.weight"], sd[f"{name}.block.0.bias"])
+    h = _ln(sd, f"{name}.block.2", h.transpose(1, 2), 1e-5).transpose(1, 2)
+    return F.mish(h) * mask
+
+
+def resnet_block(sd, name, x, mask, temb):
+    # ResnetBlock1D.forward, flow/components/decoder.py:54-59
+    h = causal_block(sd, f"{name}.block1", x, mask)
+    h = h + _lin(sd, f"{name}.mlp.1", F.mish(temb)).unsqueeze(-1)
+    h = causal_block(sd, f"{name}.block2", h, mask)
+    return h + F.conv1d(x * mask, sd[f"{name}.res_conv.weight"], sd[f"{name}.res_conv.bias"])
+
+
+def transformer_block(sd, name, x, attn_mask, heads, head_dim):
+    """BasicTransformerBlock.forward (flow/components/transformer.py:243-316) with the restated
+    diffusers-0.27.2 Attention / GELU semantics: to_q/k/v no bias, scale dh^-0.5,
+    3-D float mask ADDED to the scores, softmax, to_out[0] with bias; FF = Linear -> exact GELU -> Linear."""
+    B, T, _ = x.shape
+    h = _ln(sd, f"{name}.norm1", x, 1e-5)
+    q = F.linear(h, sd[f"{name}.attn1.to_q.weight"]).view(B, T, heads, head_dim).transpose(1, 2)
+    k = F.linear(h, sd[f"{name}.attn1.to_k.weight"]).view(B, T, heads, head_dim).transpose(1, 2)
+    v = F.linear(h, sd[f"{name}.attn1.to_v.weight"]).view(B, T, heads, head_dim).transpose(1, 2)
+    scores = torch.matmul(q, k.transpose(-2, -1)) * head_dim ** -0.5
+    if attn_mask is not None:
+        scores = scores + attn_mask.unsqueeze(1)
+    o = torch.matmul(torch.softmax(scores, dim=-1), v).transpose(1, 2).reshape(B, T, heads * head_dim)
+    x = _lin(sd, f"{name}.attn1.to_out.0", o) + x
+    h = _ln(sd, f"{name}.norm3", x, 1e-5)
+    h = _lin(sd, f"{name}.ff.net.2", F.gelu(_lin(sd, f"{name}.ff.net.0.proj", h)))
+    return h + x
+
+
+def estimator_forward(sd, cfg: FlowConfig, x, mask, mu, t, spks, cond, prefix: str = "decoder.estimator."):
+    """ConditionalDecoder.forward, flow/decoder.py:222-334, for channels=[256], causal=True.
+    x,mu,cond (B,80,T); mask (B,1,T); t (B,); spks (B,80) -> (B,80,T)."""
+    temb = sinusoidal_pos_emb(t, cfg.est_in_channels)
+    temb = _lin(sd, f"{prefix}time_mlp.linear_2", F.silu(_lin(sd, f"{prefix}time_mlp.linear_1", temb)))
+    T = x.shape[-1]
+    h = torch.cat([x, mu, spks.unsqueeze(-1).expand(-1, -1, T), cond], dim=1)
+    # the reference feeds the 0/1 float mask^T.mask as an ADDITIVE bias (decoder.py:258, H3)
+    attn_mask = torch.matmul(mask.transpose(1, 2), mask)
+
+    def tblocks(name, h):
+        h = h.transpose(1, 2)
+        for j in range(cfg.est_n_blocks):
+            h = transformer_block(sd, f"{name}.{j}", h, attn_mask, cfg.est_heads, cfg.est_head_dim)
+        return h.transpose(1, 2)
+
+    h = resnet_block(sd, f"{prefix}down_blocks.0.0", h, mask, temb)
+    h = tblocks(f"{prefix}down_blocks.0.1", h)
+    skip = h
+    h = F.conv1d(F.pad(h * mask, (2, 0)), sd[f"{prefix}down_blocks.0.2.weight"], sd[f"{prefix}down_blocks.0.2.bias"])
+    for i in range(cfg.est_mid_blocks):
+        h = resnet_block(sd, f"{prefix}mid_blocks.{i}.0", h, mask, temb)
+        h = tblocks(f"{prefix}mid_blocks.{i}.1", h)
+    h = torch.cat([h, skip], dim=1)
+    h = resnet_block(sd, f"{prefix}up_blocks.0.0", h, mask, temb)
+    h = tblocks(f"{prefix}up_blocks.0.1", h)
+    h = F.conv1d(F.pad(h * mask, (2, 0)), sd[f"{prefix}up_blocks.0.2.weight"], sd[f"{prefix}up_blocks.0.2.bias"])
+    h = causal_block(sd, f"{prefix}final_block", h, mask)
+    out = F.conv1d(h * mask, sd[f"{prefix}final_proj.weight"], sd[f"{prefix}final_proj.bias"])
+    return out * mask
+
+
+# ------------------------------------------------------------------ CFM
+def rand_noise(cfg: FlowConfig) -> torch.Tensor:
+    """CausalConditionalCFM.rand_noise (flow_matching.py:212-213): randn(1,80,15000) drawn right after
+    set_all_random_seed(0).  Restores the caller's RNG state."""
+    state = torch.get_rng_state()
+    torch.manual_seed(0)
+    z = torch.randn([1, 80, cfg.noise_len])
+    torch.set_rng_state(state)
+    return z
+
+
+def t_span_cosine(n_timesteps: int) -> torch.Tensor:
+    # flow_matching.py:237-239
+    t = torch.linspace(0, 1, n_timesteps + 1, dtype=torch.float32)
+    return 1 - torch.cos(t * 0.5 * torch.pi)
+
+
+def solve_euler(sd, cfg: FlowConfig, x, t_span, mu, mask, spks, cond, estimator=None):
+    """ConditionalCFM.solve_euler, flow_matching.py:72-124 (batch-2 CFG: row 0 cond, row 1 uncond)."""
+    if estimator is None:
+        estimator = lambda *a: estimator_forward(sd, cfg, *a)
+    t, dt = t_span[0].unsqueeze(0), t_span[1] - t_span[0]
+    T = x.size(2)
+    for step in range(1, len(t_span)):
+        x_in = torch.cat([x, x], 0)
+        mask_in = torch.cat([mask, mask], 0)
+        mu_in = torch.cat([mu, torch.zeros_like(mu)], 0)
+        t_in = torch.cat([t, t], 0)
+        spks_in = torch.cat([spks, torch.zeros_like(spks)], 0)
+        cond_in = torch.cat([cond, torch.zeros_like(cond)], 0)
+        d = estimator(x_in, mask_in, mu_in, t_in, spks_in, cond_in)
+        d, cfg_d = d[:1], d[1:]
+        d = (1.0 + cfg.inference_cfg_rate) * d - cfg.inference_cfg_rate * cfg_d
+        x = x + dt * d
+        t = t + dt
+        if step < len(t_span) - 1:
+            dt = t_span[step + 1] - t
+    return x.float()
+
+
+def cfm_forward(sd, cfg: FlowConfig, mu, mask, spks, cond, n_timesteps: int = 10, estimator=None):
+    # CausalConditionalCFM.forward, flow_matching.py:215-240
+    z = rand_noise(cfg)[:, :, :mu.size(2)]
+    return solve_euler(sd, cfg, z, t_span_cosine(n_timesteps), mu, mask, spks, cond, estimator)
+
+
+def inference(sd, cfg: FlowConfig, token, prompt_token, prompt_feat, embedding, n_timesteps: int = 10,
+              static_chunk_size: int = 0, return_mu: bool = False):
+    """CausalMaskedDiffWithXvec.inference, flow/flow.py:258-319 (batch 1).
+    token (1,Ng) prompt_token (1,Np) prompt_feat (1,Tp,80) embedding (1,D) -> mel (1,80,2*Ng)."""
+    assert token.shape[0] == 1
+    r = cfg.token_mel_ratio
+    if prompt_feat.shape[1] % r != 0:  # flow.py:279-283
+        keep = prompt_feat.shape[1] - prompt_feat.shape[1] % r
+        prompt_feat = prompt_feat[:, :keep]
+        prompt_token = prompt_token[:, : keep // r]
+    emb = F.normalize(embedding, dim=1)
+    emb = _lin(sd, "spk_embed_affine_layer", emb)
+    tok = torch.cat([prompt_token, token], dim=1).long()
+    tok_len = torch.tensor([tok.shape[1]])
+    h = F.embedding(tok, sd["input_embedding.weight"])
+    h, _ = encoder_forward(sd, cfg, h, tok_len, static_chunk_size)
+    mel_len1, mel_len2 = prompt_feat.shape[1], h.shape[1] - prompt_feat.shape[1]
+    h = _lin(sd, "encoder_proj", h)
+    conds = torch.zeros([1, mel_len1 + mel_len2, cfg.output_size])
+    conds[:, :mel_len1] = prompt_feat
+    conds = conds.transpose(1, 2)
+    mask = torch.ones(1, 1, mel_len1 + mel_len2)
+    mu = h.transpose(1, 2).contiguous()
+    feat = cfm_forward(sd, cfg, mu, mask, emb, conds, n_timesteps)
+    feat = feat[:, :, mel_len1:]
+    assert feat.shape[2] == mel_len2
+    if return_mu:
+        return feat.float(), mu, emb, conds
+    return feat.float()

@@ -1,0 +1,356 @@
+#!/usr/bin/env python3
+"""Mint the golden fixtures in tests/golden/*.npz by running the REFERENCE's own modules
+(/root/reference, read-only) on the build's key-seeded synthetic weights.
+
+Run in the build container only (the reference never travels to the GPU box):
+    python tests/golden/make_golden.py
+
+What is imported from the reference: its stage modules, as they are.  What is stubbed:
+name-only stand-ins for third-party modules that are absent here and carry NO hot-path
+arithmetic (torchmetrics, omegaconf.DictConfig, torchaudio, onnxruntime, conformer) —
+and ONE arithmetic-bearing restatement: three diffusers-0.27.2 classes
+(Attention / GELU / LoRACompatibleLinear) that flow/components/transformer.py imports.
+Estimator goldens therefore pin everything except those three classes ("parity
+unpinned" at that boundary).
+
+Fixtures hold inputs + expected outputs only (no reference source).  Weights are not
+stored: they are regenerated from cosyvoice_amd.weights (key-seeded).
+"""
+import importlib.machinery
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    m.__path__ = []
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    import transformers  # noqa: F401  (must be imported before torchaudio is stubbed: it probes __spec__)
+    from transformers import Qwen2Config, Qwen2ForCausalLM  # noqa: F401
+    import torch.nn as nn
+
+    class _Any:  # name-only
+        def __init__(self, *a, **k):
+            pass
+
+    class DictConfig(dict):
+        def __init__(self, content=None, **k):
+            super().__init__(content or {})
+
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+    _stub("torchmetrics")
+    _stub("torchmetrics.classification", MulticlassAccuracy=_Any)
+    _stub("omegaconf", DictConfig=DictConfig)
+    ta = _stub("torchaudio")
+    ta.transforms = _stub("torchaudio.transforms")
+    ta.compliance = _stub("torchaudio.compliance")
+    ta.compliance.kaldi = _stub("torchaudio.compliance.kaldi")
+    _stub("onnxruntime", InferenceSession=_Any)
+    _stub("conformer", ConformerBlock=nn.Module)
+
+    # ---- arithmetic-bearing restatement of the three diffusers 0.27.2 classes (unpinned) ----
+    class GELU(nn.Module):
+        def __init__(self, dim_in, dim_out, approximate="none"):
+            super().__init__()
+            self.proj = nn.Linear(dim_in, dim_out)
+            self.approximate = approximate
+
+        def forward(self, x):
+            return torch.nn.functional.gelu(self.proj(x), approximate=self.approximate)
+
+    class Attention(nn.Module):
+        def __init__(self, query_dim, heads=8, dim_head=64, dropout=0.0, bias=False, cross_attention_dim=None,
+                     upcast_attention=False, **kw):
+            super().__init__()
+            inner = heads * dim_head
+            self.heads, self.scale = heads, dim_head ** -0.5
+            self.to_q = nn.Linear(query_dim, inner, bias=bias)
+            self.to_k = nn.Linear(query_dim, inner, bias=bias)
+            self.to_v = nn.Linear(query_dim, inner, bias=bias)
+            self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(dropout)])
+
+        def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
+            B, T, _ = hidden_states.shape
+            h = self.heads
+            q = self.to_q(hidden_states).view(B, T, h, -1).transpose(1, 2)
+            k = self.to_k(hidden_states).view(B, T, h, -1).transpose(1, 2)
+            v = self.to_v(hidden_states).view(B, T, h, -1).transpose(1, 2)
+            s = torch.matmul(q, k.transpose(-1, -2)) * self.scale
+            if attention_mask is not None:
+                s = s + attention_mask.unsqueeze(1)
+            o = torch.matmul(s.softmax(-1), v).transpose(1, 2).reshape(B, T, -1)
+            return self.to_out[0](o)
+
+    _stub("diffusers")
+    _stub("diffusers.models")
+    _stub("diffusers.models.attention", GEGLU=_Any, GELU=GELU, AdaLayerNorm=_Any, AdaLayerNormZero=_Any,
+          ApproximateGELU=_Any)
+    _stub("diffusers.models.attention_processor", Attention=Attention)
+    _stub("diffusers.models.lora", LoRACompatibleLinear=nn.Linear)
+    _stub("diffusers.models.activations", get_activation=lambda name: {"silu": nn.SiLU(), "swish": nn.SiLU(),
+                                                                        "mish": nn.Mish(), "gelu": nn.GELU()}[name])
+    _stub("diffusers.utils")
+    _stub("diffusers.utils.torch_utils", maybe_allow_in_graph=lambda c: c)
+    sys.path.insert(0, REF)
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, {k: tuple(v.shape) for k, v in out.items()})
+
+
+def summary(t: torch.Tensor):
+    t = t.detach().float()
+    return np.array([t.mean().item(), t.abs().mean().item(), t.std().item(), t.abs().max().item()], dtype=np.float64)
+
+
+# ----------------------------------------------------------------------------- HiFT
+def build_ref_hift(cfg, sd):
+    from cosyvoice.hifigan.f0_predictor import ConvRNNF0Predictor
+    from cosyvoice.hifigan.generator import HiFTGenerator
+    f0p = ConvRNNF0Predictor(num_class=1, in_channels=cfg.in_channels, cond_channels=cfg.f0_cond_channels)
+    m = HiFTGenerator(in_channels=cfg.in_channels, base_channels=cfg.base_channels, nb_harmonics=cfg.nb_harmonics,
+                      sampling_rate=cfg.sampling_rate, nsf_alpha=cfg.nsf_alpha, nsf_sigma=cfg.nsf_sigma,
+                      nsf_voiced_threshold=cfg.nsf_voiced_threshold, upsample_rates=list(cfg.upsample_rates),
+                      upsample_kernel_sizes=list(cfg.upsample_kernel_sizes),
+                      istft_params={"n_fft": cfg.n_fft, "hop_len": cfg.hop_len},
+                      resblock_kernel_sizes=list(cfg.resblock_kernel_sizes),
+                      resblock_dilation_sizes=[list(d) for d in cfg.resblock_dilation_sizes],
+                      source_resblock_kernel_sizes=list(cfg.source_resblock_kernel_sizes),
+                      source_resblock_dilation_sizes=[list(d) for d in cfg.source_resblock_dilation_sizes],
+                      lrelu_slope=cfg.lrelu_slope, audio_limit=cfg.audio_limit, f0_predictor=f0p)
+    missing, unexpected = m.load_state_dict(sd, strict=True), None
+    return m.eval()
+
+
+def synth_mel(batch, frames, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.clamp(torch.randn(batch, 80, frames, generator=g) * 2.0 - 6.0, -11.5, 2.0)
+
+
+def golden_hift():
+    from cosyvoice_amd.config import HiftConfig
+    from cosyvoice_amd.weights import hift_state_dict
+    for tag, cfg, frames in (("tiny", HiftConfig.tiny(), 24), ("v2", HiftConfig.v2(), 20), ("v1", HiftConfig.v1(), 16)):
+        sd = hift_state_dict(cfg)
+        m = build_ref_hift(cfg, sd)
+        mel = synth_mel(1, frames, seed=11)
+        g = torch.Generator().manual_seed(12)
+        s = torch.randn(1, 1, frames * cfg.total_upsample, generator=g) * 0.05
+        with torch.inference_mode():
+            wav = m.decode(x=mel, s=s)
+            f0 = m.f0_predictor(mel)
+            # SineGen + source module with the reference's own RNG: capture its draws by seeding
+            torch.manual_seed(1234)
+            f0_up = m.f0_upsamp(f0[:, None]).transpose(1, 2)
+            src, _, _ = m.m_source(f0_up)
+            # replay the reference's draw order to recover the randoms it consumed (generator.py:149-163)
+            torch.manual_seed(1234)
+            from torch.distributions.uniform import Uniform
+            pv = Uniform(low=-np.pi, high=np.pi).sample(sample_shape=(1, cfg.nb_harmonics + 1, 1))
+            noise = torch.randn(1, cfg.nb_harmonics + 1, f0_up.shape[1])
+        save(f"hift_{tag}", mel=mel, s=s, wav=wav, f0=f0, src=src.transpose(1, 2), phase_vec=pv, noise=noise)
+
+
+# ----------------------------------------------------------------------------- flow
+def build_ref_flow(cfg, sd):
+    from omegaconf import DictConfig
+    from cosyvoice.flow.decoder import ConditionalDecoder
+    from cosyvoice.flow.flow import CausalMaskedDiffWithXvec
+    from cosyvoice.flow.flow_matching import CausalConditionalCFM
+    from cosyvoice.transformer.upsample_encoder import UpsampleConformerEncoder
+    enc = UpsampleConformerEncoder(output_size=cfg.enc_dim, attention_heads=cfg.enc_heads,
+                                   linear_units=cfg.enc_linear_units, num_blocks=cfg.enc_blocks, dropout_rate=0.1,
+                                   positional_dropout_rate=0.1, attention_dropout_rate=0.1, normalize_before=True,
+                                   input_layer="linear", pos_enc_layer_type="rel_pos_espnet",
+                                   selfattention_layer_type="rel_selfattn", input_size=cfg.input_size,
+                                   use_cnn_module=False, macaron_style=False)
+    if cfg.enc_up_blocks != 4:
+        enc.up_encoders = torch.nn.ModuleList(list(enc.up_encoders)[:cfg.enc_up_blocks])
+    est = ConditionalDecoder(in_channels=cfg.est_in_channels, out_channels=cfg.output_size, causal=True,
+                             channels=[cfg.est_channels], dropout=0.0, attention_head_dim=cfg.est_head_dim,
+                             n_blocks=cfg.est_n_blocks, num_mid_blocks=cfg.est_mid_blocks, num_heads=cfg.est_heads,
+                             act_fn="gelu")
+    cfm = CausalConditionalCFM(in_channels=240, n_spks=1, spk_emb_dim=80,
+                               cfm_params=DictConfig({"sigma_min": 1e-06, "solver": "euler", "t_scheduler": "cosine",
+                                                      "training_cfg_rate": 0.2, "inference_cfg_rate": cfg.inference_cfg_rate,
+                                                      "reg_loss_type": "l1"}), estimator=est)
+    flow = CausalMaskedDiffWithXvec(input_size=cfg.input_size, output_size=cfg.output_size,
+                                    spk_embed_dim=cfg.spk_embed_dim, output_type="mel", vocab_size=cfg.vocab_size,
+                                    input_frame_rate=cfg.input_frame_rate, only_mask_loss=True,
+                                    token_mel_ratio=cfg.token_mel_ratio, pre_lookahead_len=cfg.pre_lookahead_len,
+                                    encoder=enc, decoder=cfm)
+    flow.load_state_dict(sd, strict=True)
+    return flow.eval()
+
+
+def golden_flow():
+    from cosyvoice_amd.config import FlowConfig
+    from cosyvoice_amd.weights import flow_state_dict
+    cfg = FlowConfig.tiny()
+    sd = flow_state_dict(cfg)
+    flow = build_ref_flow(cfg, sd)
+    g = torch.Generator().manual_seed(21)
+    n_p, n_g = 6, 10
+    token = torch.randint(0, cfg.vocab_size, (1, n_g), generator=g, dtype=torch.int32)
+    prompt_token = torch.randint(0, cfg.vocab_size, (1, n_p), generator=g, dtype=torch.int32)
+    prompt_feat = torch.clamp(torch.randn(1, 2 * n_p, 80, generator=g) * 2 - 6, -11.5, 2.0)
+    embedding = torch.randn(1, cfg.spk_embed_dim, generator=g)
+    with torch.inference_mode():
+        rn = flow.decoder.rand_noise[:, :, :64].clone()
+        # (a) estimator alone
+        T = 2 * (n_p + n_g)
+        x = torch.randn(2, 80, T, generator=g)
+        mu = torch.randn(2, 80, T, generator=g)
+        cond = torch.randn(2, 80, T, generator=g)
+        spks = torch.randn(2, 80, generator=g)
+        t = torch.tensor([0.3, 0.3])
+        mask = torch.ones(2, 1, T)
+        est_out = flow.decoder.estimator(x, mask, mu, t, spks, cond)
+        # (b) encoder alone, full attention and chunk-16 attention
+        xs = torch.randn(1, n_p + n_g, cfg.input_size, generator=g)
+        lens = torch.tensor([n_p + n_g])
+        flow.encoder.static_chunk_size = 0
+        enc_full, _ = flow.encoder(xs, lens)
+        flow.encoder.static_chunk_size = 4
+        enc_chunk, _ = flow.encoder(xs, lens)
+        # (c) whole inference, CosyVoiceModel wiring (static_chunk_size 0) and CosyVoice2Model wiring (chunk 4 here)
+        flow.encoder.static_chunk_size = 0
+        mel_full, _ = flow.inference(token=token, token_len=torch.tensor([n_g]), prompt_token=prompt_token,
+                                     prompt_token_len=torch.tensor([n_p]), prompt_feat=prompt_feat,
+                                     prompt_feat_len=torch.tensor([2 * n_p]), embedding=embedding)
+        flow.encoder.static_chunk_size = 4
+        mel_chunk, _ = flow.inference(token=token, token_len=torch.tensor([n_g]), prompt_token=prompt_token,
+                                      prompt_token_len=torch.tensor([n_p]), prompt_feat=prompt_feat,
+                                      prompt_feat_len=torch.tensor([2 * n_p]), embedding=embedding)
+    save("flow_tiny", token=token, prompt_token=prompt_token, prompt_feat=prompt_feat, embedding=embedding,
+         rand_noise_head=rn, est_x=x, est_mu=mu, est_cond=cond, est_spks=spks, est_t=t, est_out=est_out,
+         enc_in=xs, enc_full=enc_full, enc_chunk4=enc_chunk, mel_full=mel_full, mel_chunk4=mel_chunk)
+
+    # full-shape single transformer block + resnet block of the estimator (T=64) for layer-level pinning
+    cfgf = FlowConfig(est_n_blocks=1, est_mid_blocks=1, enc_blocks=1, enc_up_blocks=1, vocab_size=64)
+    sdf = flow_state_dict(cfgf)
+    flowf = build_ref_flow(cfgf, sdf)
+    with torch.inference_mode():
+        T = 64
+        x = torch.randn(2, 80, T, generator=g); mu = torch.randn(2, 80, T, generator=g)
+        cond = torch.randn(2, 80, T, generator=g); spks = torch.randn(2, 80, generator=g)
+        t = torch.tensor([0.7, 0.7]); mask = torch.ones(2, 1, T)
+        out = flowf.decoder.estimator(x, mask, mu, t, spks, cond)
+    save("flow_est_1block", est_x=x, est_mu=mu, est_cond=cond, est_spks=spks, est_t=t, est_out=out)
+
+
+# ----------------------------------------------------------------------------- llm
+def build_ref_llm(cfg, sd):
+    from cosyvoice.llm.llm import Qwen2Encoder, Qwen2LM
+    from cosyvoice.utils.common import ras_sampling
+    d = tempfile.mkdtemp()
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump(cfg.hf_config_dict(), f)
+    enc = Qwen2Encoder(d)
+    lm = Qwen2LM(llm_input_size=cfg.hidden_size, llm_output_size=cfg.hidden_size, speech_token_size=cfg.speech_token_size,
+                 llm=enc, sampling=ras_sampling)
+    missing = lm.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys, missing.unexpected_keys
+    assert all("rotary" in k or "inv_freq" in k for k in missing.missing_keys), missing.missing_keys
+    return lm.eval()
+
+
+def golden_llm():
+    from cosyvoice_amd.config import LlmConfig
+    from cosyvoice_amd.weights import llm_state_dict
+    cfg = LlmConfig.tiny()
+    sd = llm_state_dict(cfg)
+    lm = build_ref_llm(cfg, sd)
+    g = torch.Generator().manual_seed(31)
+    text = torch.randint(0, cfg.vocab_size, (1, 6), generator=g, dtype=torch.int32)
+    prompt_text = torch.randint(0, cfg.vocab_size, (1, 4), generator=g, dtype=torch.int32)
+    prompt_speech = torch.randint(0, cfg.speech_token_size, (1, 9), generator=g, dtype=torch.int32)
+    forced = torch.randint(0, cfg.speech_token_size, (12,), generator=g).tolist()
+    # teacher-forced log-probs through the reference's own forward_one_step / llm_decoder (llm.py:861-874)
+    with torch.inference_mode():
+        t = torch.cat([prompt_text, text], dim=1)
+        te = lm.llm.model.model.embed_tokens(t)
+        sos = lm.llm_embedding.weight[lm.sos_eos].reshape(1, 1, -1)
+        task = lm.llm_embedding.weight[lm.task_id].reshape(1, 1, -1)
+        pe = lm.speech_embedding(prompt_speech)
+        lm_input = torch.cat([sos, te, task, pe], dim=1)
+        cache = None
+        logps = []
+        past = 0
+        for i in range(len(forced) + 1):
+            # NOTE: the reference's forward_one_step passes attention_mask = masks[:, -1, :], i.e. a mask of
+            # the CURRENT chunk length only (llm.py:755,862-864).  transformers<=4.5x ignores an all-ones mask
+            # (full causal attention over the cache — also what the reference's own graph path does,
+            # qwen2_5.py:154-162: no mask at decode); the transformers 5.15 installed here mis-reads the short
+            # mask at decode steps.  The golden therefore calls the same HF model with a full-length mask.
+            L = lm_input.shape[1]
+            outs = lm.llm.model(inputs_embeds=lm_input, attention_mask=torch.ones(1, past + L, dtype=torch.bool),
+                                output_hidden_states=True, return_dict=True, use_cache=True, past_key_values=cache)
+            y, cache = outs.hidden_states[-1], outs.past_key_values
+            past += L
+            logps.append(lm.llm_decoder(y[:, -1]).log_softmax(dim=-1))
+            if i < len(forced):
+                lm_input = lm.speech_embedding.weight[forced[i]].reshape(1, 1, -1)
+        logps = torch.cat(logps, 0)
+    save("llm_tiny", text=text, prompt_text=prompt_text, prompt_speech=prompt_speech, forced=np.array(forced),
+         logps=logps)
+
+    # sampler candidate sets (deterministic part of nucleus_sampling, utils/common.py:126-137)
+    from cosyvoice.utils import common as C
+    scores = torch.randn(4, 300, generator=g) * 2.0
+    cand = []
+    for r in range(4):
+        sv, si = scores[r].softmax(dim=0).sort(descending=True, stable=True)
+        cum, n = 0.0, 0
+        while n < 25 and cum < 0.8:
+            cum += sv[n].item(); n += 1
+        row = np.full(25, -1, dtype=np.int64); row[:n] = si[:n].numpy()
+        cand.append(row)
+    save("sampler", scores=scores, candidates=np.stack(cand))
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    install_stubs()
+    which = sys.argv[1:] or ["hift", "flow", "llm"]
+    if "hift" in which:
+        golden_hift()
+    if "flow" in which:
+        golden_flow()
+    if "llm" in which:
+        golden_llm()
+
+
+if __name__ == "__main__":
+    main()

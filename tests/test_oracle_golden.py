@@ -1,0 +1,107 @@
+"""CPU: the oracle (oracle/*.py) against the golden fixtures minted from the reference itself
+(tests/golden/make_golden.py).  fp32 tolerance 1e-5 abs per SURVEY.md §8d."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from cosyvoice_amd.config import FlowConfig, HiftConfig, LlmConfig
+from cosyvoice_amd.weights import flow_state_dict, hift_state_dict, llm_state_dict
+from oracle import flow as of
+from oracle import hift as oh
+from oracle import llm as ol
+
+
+def _load(golden_dir, name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, name + ".npz")).items()}
+
+
+@pytest.mark.parametrize("tag,cfg", [("tiny", HiftConfig.tiny()), ("v2", HiftConfig.v2()), ("v1", HiftConfig.v1())])
+def test_hift_decode_f0_source(golden_dir, tag, cfg):
+    g = _load(golden_dir, f"hift_{tag}")
+    sd = hift_state_dict(cfg)
+    wav = oh.decode(sd, cfg, g["mel"], g["s"])
+    assert (wav - g["wav"]).abs().max().item() < 1e-5
+    assert wav.abs().max().item() < cfg.audio_limit  # fixture is not saturated by the clamp
+    f0 = oh.f0_predictor(sd, g["mel"])
+    assert (f0 - g["f0"]).abs().max().item() < 1e-3  # values up to ~130 Hz: 1e-5 relative
+    f0u = f0[:, None].repeat_interleave(cfg.total_upsample, dim=2).transpose(1, 2)
+    src = oh.source_module(sd, cfg, f0u, g["phase_vec"], g["noise"]).transpose(1, 2)
+    assert (src - g["src"]).abs().max().item() < 1e-4  # fp32 cumsum ordering (H4)
+
+
+def test_hift_source_scan_fp64_close_to_fp32():
+    cfg = HiftConfig.v2()
+    sd = hift_state_dict(cfg)
+    f0 = torch.full((1, 1, 20), 220.0)
+    f0u = f0.repeat_interleave(cfg.total_upsample, dim=2).transpose(1, 2)
+    ph, nz = oh.draw_source_randoms(cfg, 1, f0u.shape[1], seed=3)
+    a = oh.source_module(sd, cfg, f0u, ph, nz, torch.float32)
+    b = oh.source_module(sd, cfg, f0u, ph, nz, torch.float64)
+    assert (a - b).abs().max().item() < 5e-3
+
+
+def test_flow_estimator_encoder_inference(golden_dir):
+    cfg = FlowConfig.tiny()
+    sd = flow_state_dict(cfg)
+    g = _load(golden_dir, "flow_tiny")
+    T = g["est_x"].shape[-1]
+    out = of.estimator_forward(sd, cfg, g["est_x"], torch.ones(2, 1, T), g["est_mu"], g["est_t"], g["est_spks"], g["est_cond"])
+    assert (out - g["est_out"]).abs().max().item() < 1e-5
+    lens = torch.tensor([g["enc_in"].shape[1]])
+    e, _ = of.encoder_forward(sd, cfg, g["enc_in"], lens, 0)
+    assert (e - g["enc_full"]).abs().max().item() < 1e-5
+    e, _ = of.encoder_forward(sd, cfg, g["enc_in"], lens, 4)
+    assert (e - g["enc_chunk4"]).abs().max().item() < 1e-5
+    assert (of.rand_noise(cfg)[:, :, :64] - g["rand_noise_head"]).abs().max().item() == 0.0
+    m = of.inference(sd, cfg, g["token"], g["prompt_token"], g["prompt_feat"], g["embedding"], static_chunk_size=0)
+    assert (m - g["mel_full"]).abs().max().item() < 1e-5
+    m = of.inference(sd, cfg, g["token"], g["prompt_token"], g["prompt_feat"], g["embedding"], static_chunk_size=4)
+    assert (m - g["mel_chunk4"]).abs().max().item() < 1e-5
+
+
+def test_flow_estimator_full_width_block(golden_dir):
+    cfg = FlowConfig(est_n_blocks=1, est_mid_blocks=1, enc_blocks=1, enc_up_blocks=1, vocab_size=64)
+    sd = flow_state_dict(cfg)
+    g = _load(golden_dir, "flow_est_1block")
+    out = of.estimator_forward(sd, cfg, g["est_x"], torch.ones(2, 1, 64), g["est_mu"], g["est_t"], g["est_spks"], g["est_cond"])
+    assert (out - g["est_out"]).abs().max().item() < 1e-5
+
+
+def test_rand_noise_known_head():
+    # CausalConditionalCFM.rand_noise starts [-1.12584, -1.15236, -0.25058, ...]
+    z = of.rand_noise(FlowConfig())
+    assert z.shape == (1, 80, 15000)
+    assert torch.allclose(z[0, 0, :3], torch.tensor([-1.12584, -1.15236, -0.25058]), atol=1e-5)
+
+
+def test_llm_teacher_forced_logp(golden_dir):
+    cfg = LlmConfig.tiny()
+    sd = llm_state_dict(cfg)
+    g = _load(golden_dir, "llm_tiny")
+    forced = g["forced"].tolist()
+    lp = []
+    rnd = random.Random(0)
+    toks = list(ol.lm_inference(sd, cfg, g["text"], g["prompt_text"], g["prompt_speech"],
+                                uniforms=lambda: (rnd.random(), rnd.random()), forced_tokens=forced, collect_logp=lp))
+    assert toks == forced
+    lp = torch.stack(lp)
+    assert (lp - g["logps"][: lp.shape[0]]).abs().max().item() < 1e-4
+
+
+def test_sampler_candidates(golden_dir):
+    g = _load(golden_dir, "sampler")
+    for r in range(g["scores"].shape[0]):
+        _, idx = ol.nucleus_candidates(g["scores"][r])
+        c = g["candidates"][r]
+        assert idx.tolist() == c[c >= 0].tolist()
+
+
+def test_ras_repetition_fallback():
+    scores = torch.zeros(50)
+    scores[7] = 10.0  # nucleus always picks 7
+    assert ol.ras_sampling(scores, [1, 2, 3], (0.5, 0.999999)) == 7
+    # 7 already in the window -> falls back to sampling the full distribution with the second uniform
+    assert ol.ras_sampling(scores, [7, 2, 3], (0.5, 0.0)) == 0
