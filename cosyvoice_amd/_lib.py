@@ -1,0 +1,103 @@
+"""ctypes binding of libcosyvoice_amd.so (the C ABI declared in include/cosyvoice_amd.h).
+
+The product path has NO fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcosyvoice_amd.so")
+
+CV_F32, CV_BF16, CV_F16 = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_SILU, ACT_MISH, ACT_LEAKY, ACT_ELU, ACT_SNAKE, ACT_TANH, ACT_SWIGLU = range(9)
+OUT_ROWMAJOR, OUT_QKV = 0, 1
+
+_i32, _i64, _f32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class GemmParams(C.Structure):
+    _fields_ = [
+        ("dtype", _i32), ("M", _i32), ("N", _i32), ("K", _i32), ("batch", _i32), ("batch_inner", _i32),
+        ("A", _vp), ("a_bs0", _i64), ("a_bs1", _i64), ("lda", _i32), ("a_rows", _i32),
+        ("cin", _i32), ("a_row_stride", _i32), ("tap_base", _i32), ("tap_step", _i32),
+        ("W", _vp), ("w_bs0", _i64), ("w_bs1", _i64), ("ldw", _i32),
+        ("bias", _vp),
+        ("res", _vp), ("res_bs0", _i64), ("res_bs1", _i64), ("ldres", _i32),
+        ("res2", _vp), ("ldres2", _i32),
+        ("out_scale", _f32),
+        ("act", _i32), ("act_param", _vp), ("act_slope", _f32),
+        ("out_f32", _vp), ("o32_bs0", _i64), ("o32_bs1", _i64), ("ldo32", _i32),
+        ("out_act", _vp), ("oa_bs0", _i64), ("oa_bs1", _i64), ("ldoa", _i32),
+        ("out_row_stride", _i32), ("out_row_off", _i32), ("out_rows", _i32),
+        ("out_mode", _i32),
+        ("q_cols", _i32), ("k_cols", _i32), ("q_scale", _f32),
+        ("k_out", _vp), ("k_bs", _i64), ("ldk", _i32),
+        ("vt_out", _vp), ("vt_heads", _i32), ("vt_ld", _i32),
+    ]
+
+
+class NormParams(C.Structure):
+    _fields_ = [
+        ("rows", _i32), ("dim", _i32), ("rms", _i32), ("eps", _f32),
+        ("x", _vp), ("ldx", _i32),
+        ("gamma", _vp), ("beta", _vp),
+        ("add", _vp), ("add_ld", _i32), ("rows_per_group", _i32),
+        ("act", _i32), ("out_scale", _f32), ("out_dtype", _i32),
+        ("out_f32", _vp), ("ldo32", _i32),
+        ("out_act", _vp), ("ldoa", _i32),
+    ]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [
+        ("dtype", _i32), ("B", _i32), ("H", _i32), ("Hkv", _i32), ("Tq", _i32), ("Tk", _i32),
+        ("q", _vp), ("q_bs", _i64), ("ldq", _i32),
+        ("k", _vp), ("k_bs", _i64), ("ldk", _i32),
+        ("vt", _vp), ("vt_ld", _i32),
+        ("out", _vp), ("o_bs", _i64), ("ldo", _i32),
+        ("scale", _f32),
+        ("klen", _vp), ("chunk", _i32), ("causal", _i32), ("causal_off", _i32),
+        ("bias", _vp), ("bias_bs", _i64), ("bias_hs", _i64), ("bias_ld", _i32),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library or fail loudly (no CPU fallback exists in the product path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -m cosyvoice_amd.build` (hipcc, gfx950). "
+                "cosyvoice_amd has no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.cv_arch.restype = C.c_char_p
+        for name, st in (("gemm", GemmParams), ("norm", NormParams), ("attn", AttnParams)):
+            fn = getattr(_lib, f"cv_sizeof_{name}_params")
+            if fn() != C.sizeof(st):
+                raise RuntimeError(f"ABI mismatch for cv_{name}_params: C {fn()} vs ctypes {C.sizeof(st)}")
+    return _lib
+
+
+EXPORTS = ["cv_version", "cv_arch", "cv_gemm", "cv_layernorm", "cv_attention",
+           "cv_sizeof_gemm_params", "cv_sizeof_norm_params", "cv_sizeof_attn_params"]
+
+TORCH_DT = {torch.float32: CV_F32, torch.bfloat16: CV_BF16, torch.float16: CV_F16}
+DT_TORCH = {v: k for k, v in TORCH_DT.items()}
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with cv_status {rc}")

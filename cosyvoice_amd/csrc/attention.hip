@@ -1,0 +1,244 @@
+// cv_attention: flash attention for gfx950, head_dim 64, 16-bit operands (bf16 / fp16), fp32 softmax + accumulation.
+//
+// Workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries (two 16-wide MFMA column tiles).
+// Scores are computed TRANSPOSED, S^T = K . Q^T (MFMA rows = keys, cols = queries), so that
+//   * a lane holds 16 keys of ONE query per 64-key tile: the softmax row reduction is in-lane + 2 cross-lane steps;
+//   * the S^T accumulator registers are, after exp and 16-bit packing, directly the B operand of O^T += V^T . P^T
+//     (k-slot (g,j<4) = key 16*kt0+4g+j, (g,j>=4) = key 16*kt1+4g+j-4): no LDS round trip for P;
+//   * V arrives pre-transposed (V^T [d][key], written by the QKV GEMM epilogue), so its A fragment is two 8-byte
+//     LDS reads per lane from a [64 d][144 B] image (pitch 144 B: conflict-free for ds_read_b64).
+// K / V^T tiles (64 keys) are staged through LDS, double-buffered with register prefetch (one barrier per tile).
+#include "cv_device.h"
+
+namespace {
+
+constexpr int KT_BYTES = 8192;        // K tile: 4 key-tiles x 2 k-steps x 1 KiB fragment blocks
+constexpr int VT_PITCH = 144;         // bytes per d-row of the V^T tile (128 data + 16 pad)
+constexpr int VT_BYTES = 64 * VT_PITCH;
+constexpr int STAGE_BYTES = KT_BYTES + VT_BYTES;
+constexpr float NEG_BIG = -1e30f;
+
+template <int DT>
+__global__ __launch_bounds__(256) void attn_kernel(const cv_attn_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lq = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int hk = h / (p.H / p.Hkv);
+  const int q_wg = blockIdx.x * 128;
+  const int q0 = q_wg + wid * 32;
+
+  const uint16_t* Q = (const uint16_t*)p.q + (int64_t)b * p.q_bs + h * 64;
+  const uint16_t* Kp = (const uint16_t*)p.k + (int64_t)b * p.k_bs + hk * 64;
+  const uint16_t* Vt = (const uint16_t*)p.vt + (int64_t)(b * p.Hkv + hk) * 64 * p.vt_ld;
+  const int klen = p.klen ? min(p.klen[b], p.Tk) : p.Tk;
+
+  // keys this workgroup can ever need
+  int limit = klen;
+  const int q_max = min(p.Tq, q_wg + 128) - 1;
+  if (p.causal) limit = min(limit, q_max + p.causal_off + 1);
+  if (p.chunk > 0) limit = min(limit, (q_max / p.chunk + 1) * p.chunk);
+  const int ntiles = (limit + 63) >> 6;
+
+  // ---- Q fragments (B operand of S^T): lane = query (lq), d chunk = ks*4 + lg
+  uint4 qf[2][2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int row = q0 + qt * 16 + lq;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[qt][ks] = make_uint4(0, 0, 0, 0);
+      if (row < p.Tq) qf[qt][ks] = *(const uint4*)(Q + (int64_t)row * p.ldq + (ks * 4 + lg) * 8);
+    }
+  }
+
+  uint4 rk[2], rv[2];
+  auto load_tile = [&](int t) {
+    const int j0 = t << 6;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = i * 256 + tid;
+      const int r = c >> 3, dc = c & 7;
+      // K: r = key within tile, dc = d chunk
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (j0 + r < klen) v = *(const uint4*)(Kp + (int64_t)(j0 + r) * p.ldk + dc * 8);
+      rk[i] = v;
+      // V^T: r = d row, dc = key chunk (8 keys); zero every key >= klen (0 * garbage must not become NaN)
+      const int kbase = j0 + dc * 8;
+      uint4 w = make_uint4(0, 0, 0, 0);
+      if (kbase < klen) {
+        w = *(const uint4*)(Vt + (int64_t)r * p.vt_ld + kbase);
+        const int nvalid = klen - kbase;  // >= 1
+        if (nvalid < 8) {
+          uint32_t* u = (uint32_t*)&w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int k0 = 2 * e;
+            if (k0 >= nvalid) u[e] = 0;
+            else if (k0 + 1 >= nvalid) u[e] &= 0xFFFFu;
+          }
+        }
+      }
+      rv[i] = w;
+    }
+  };
+  auto store_tile = [&](int s) {
+    char* sk = smem + s * STAGE_BYTES;
+    char* sv = sk + KT_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = i * 256 + tid;
+      const int r = c >> 3, dc = c & 7;
+      *(uint4*)(sk + (((r >> 4) * 2 + (dc >> 2)) << 10) + ((dc & 3) << 8) + ((r & 15) << 4)) = rk[i];
+      *(uint4*)(sv + r * VT_PITCH + dc * 16) = rv[i];
+    }
+  };
+
+  f32x4_t oacc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) oacc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float mrun[2] = {NEG_BIG, NEG_BIG}, lrun[2] = {0.f, 0.f};
+  const float sc = p.scale * 1.4426950408889634f;  // fold log2(e): softmax via exp2
+
+  if (ntiles > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int s = t & 1;
+    if (t + 1 < ntiles) load_tile(t + 1);
+    const char* sk = smem + s * STAGE_BYTES;
+    const char* sv = sk + KT_BYTES;
+    const int j0 = t << 6;
+
+    // ---- S^T = K . Q^T
+    f32x4_t sacc[4][2];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const uint4 k0 = *(const uint4*)(sk + ((kt * 2 + 0) << 10) + lane * 16);
+      const uint4 k1 = *(const uint4*)(sk + ((kt * 2 + 1) << 10) + lane * 16);
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        a = mfma_block<DT>(k0, qf[qt][0], a);
+        a = mfma_block<DT>(k1, qf[qt][1], a);
+        sacc[kt][qt] = a;
+      }
+    }
+
+    // ---- scale, bias, masks, online softmax (per query = per lane column)
+    uint4 pf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int i = q0 + qt * 16 + lq;
+      int jlim = klen;
+      if (p.causal) jlim = min(jlim, i + p.causal_off + 1);
+      if (p.chunk > 0) jlim = min(jlim, (i / p.chunk + 1) * p.chunk);
+      const float* brow = nullptr;
+      if (p.bias && i < p.Tq) brow = p.bias + (int64_t)b * p.bias_bs + (int64_t)h * p.bias_hs + (int64_t)i * p.bias_ld;
+      float mx = NEG_BIG;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = j0 + kt * 16 + 4 * lg + r;
+          float v = sacc[kt][qt][r] * sc;
+          if (brow && j < jlim) v += brow[j] * 1.4426950408889634f;
+          v = (j < jlim) ? v : NEG_BIG;
+          sacc[kt][qt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(mrun[qt], mx);
+      const float alpha = exp2f(mrun[qt] - mnew);
+      mrun[qt] = mnew;
+      float ls = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = exp2f(sacc[kt][qt][r] - mnew);
+          sacc[kt][qt][r] = e;
+          ls += e;
+        }
+      }
+      lrun[qt] = lrun[qt] * alpha + ls;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        oacc[dt][qt][0] *= alpha; oacc[dt][qt][1] *= alpha; oacc[dt][qt][2] *= alpha; oacc[dt][qt][3] *= alpha;
+      }
+      // P^T fragments: k-step s2 covers key tiles 2*s2 (elements 0..3) and 2*s2+1 (elements 4..7)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        uint4 f;
+        f.x = pack2<DT>(sacc[2 * s2][qt][0], sacc[2 * s2][qt][1]);
+        f.y = pack2<DT>(sacc[2 * s2][qt][2], sacc[2 * s2][qt][3]);
+        f.z = pack2<DT>(sacc[2 * s2 + 1][qt][0], sacc[2 * s2 + 1][qt][1]);
+        f.w = pack2<DT>(sacc[2 * s2 + 1][qt][2], sacc[2 * s2 + 1][qt][3]);
+        pf[qt][s2] = f;
+      }
+    }
+
+    // ---- O^T += V^T . P^T
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const char* vrow = sv + (dt * 16 + lq) * VT_PITCH + lg * 8;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const uint2 lo = *(const uint2*)(vrow + s2 * 64);
+        const uint2 hi = *(const uint2*)(vrow + s2 * 64 + 32);
+        const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = mfma_block<DT>(vf, pf[qt][s2], oacc[dt][qt]);
+      }
+    }
+
+    if (t + 1 < ntiles) store_tile(s ^ 1);
+    __syncthreads();
+  }
+
+  // ---- finalize: O[q][d] = O^T / l ; lane holds q = lq, d = dt*16 + 4*lg + r
+  uint16_t* O = (uint16_t*)p.out + (int64_t)b * p.o_bs + h * 64;
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float l = lrun[qt];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    const int i = q0 + qt * 16 + lq;
+    if (i >= p.Tq) continue;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      uint2 u;
+      u.x = pack2<DT>(oacc[dt][qt][0] * inv, oacc[dt][qt][1] * inv);
+      u.y = pack2<DT>(oacc[dt][qt][2] * inv, oacc[dt][qt][3] * inv);
+      *(uint2*)(O + (int64_t)i * p.ldo + dt * 16 + 4 * lg) = u;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int cv_attention(const cv_attn_params* pp, void* stream) {
+  if (!pp) return CV_ERR_ARG;
+  const cv_attn_params& p = *pp;
+  if (p.dtype != CV_BF16 && p.dtype != CV_F16) return CV_ERR_UNSUPPORTED;
+  if (p.B <= 0 || p.H <= 0 || p.Hkv <= 0 || (p.H % p.Hkv) || p.Tq <= 0 || p.Tk <= 0) return CV_ERR_ARG;
+  if (!p.q || !p.k || !p.vt || !p.out) return CV_ERR_ARG;
+  if ((p.ldq & 7) || (p.ldk & 7) || (p.vt_ld & 7) || (p.ldo & 3) || (p.q_bs & 7) || (p.k_bs & 7) || (p.o_bs & 3)) return CV_ERR_ARG;
+  if (p.vt_ld < p.Tk) return CV_ERR_ARG;
+  if (((uintptr_t)p.q & 15) || ((uintptr_t)p.k & 15) || ((uintptr_t)p.vt & 15) || ((uintptr_t)p.out & 7)) return CV_ERR_ARG;
+  dim3 grid((p.Tq + 127) / 128, p.H, p.B);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = 2 * STAGE_BYTES;
+  if (p.dtype == CV_BF16) hipLaunchKernelGGL(attn_kernel<CV_BF16>, grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL(attn_kernel<CV_F16>, grid, dim3(256), lds, st, p);
+  CV_CHECK_LAUNCH();
+  return CV_OK;
+}

@@ -1,0 +1,96 @@
+// Device-side helpers shared by the gfx950 kernels (wave64, MFMA 16x16, 16-byte LDS chunks).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/cosyvoice_amd.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define CV_CHECK_LAUNCH()                                  \
+  do {                                                     \
+    hipError_t e__ = hipGetLastError();                    \
+    if (e__ != hipSuccess) return CV_ERR_LAUNCH;           \
+  } while (0)
+
+template <typename To, typename From>
+__device__ __forceinline__ To bitcast(const From& f) {
+  static_assert(sizeof(To) == sizeof(From), "size");
+  To t;
+  __builtin_memcpy(&t, &f, sizeof(To));
+  return t;
+}
+
+// ---- 16-bit conversions (RNE; hipcc lowers the casts to v_cvt_pk_bf16_f32 / v_cvt_f16_f32) ----
+template <int DT> struct Elem16;
+template <> struct Elem16<CV_BF16> {
+  static __device__ __forceinline__ uint16_t from_f32(float f) { return bitcast<uint16_t>((__bf16)f); }
+  static __device__ __forceinline__ float to_f32(uint16_t u) { return bitcast<float>((uint32_t)u << 16); }
+};
+template <> struct Elem16<CV_F16> {
+  static __device__ __forceinline__ uint16_t from_f32(float f) { return bitcast<uint16_t>((_Float16)f); }
+  static __device__ __forceinline__ float to_f32(uint16_t u) { return (float)bitcast<_Float16>(u); }
+};
+
+template <int DT>
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  return (uint32_t)Elem16<DT>::from_f32(a) | ((uint32_t)Elem16<DT>::from_f32(b) << 16);
+}
+
+// One "block" MFMA step over the K extent of four 16-byte chunks (32 k for 16-bit, 16 k for f32).
+// a: fragment of the operand whose rows become D rows; b: fragment whose rows become D columns.
+// Lane l holds row (l&15), chunk (l>>4) of each.  D: col = l&15, row = 4*(l>>4) + reg.
+template <int DT>
+__device__ __forceinline__ f32x4_t mfma_block(const uint4& a, const uint4& b, f32x4_t c) {
+  if constexpr (DT == CV_BF16) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(bitcast<bf16x8_t>(a), bitcast<bf16x8_t>(b), c, 0, 0, 0);
+  } else if constexpr (DT == CV_F16) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(bitcast<f16x8_t>(a), bitcast<f16x8_t>(b), c, 0, 0, 0);
+  } else {
+    // exact-f32 MFMA (v_mfma_f32_16x16x4_f32); element j of every lane's float4 forms k-step j
+    const float4 fa = bitcast<float4>(a), fb = bitcast<float4>(b);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.x, fb.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.y, fb.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.z, fb.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.w, fb.w, c, 0, 0, 0);
+    return c;
+  }
+}
+
+// ---- activations (fp32) ----
+__device__ __forceinline__ float act_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float act_silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float act_mish(float x) {
+  // x * tanh(softplus(x)); softplus threshold 20 as torch
+  float sp = x > 20.0f ? x : log1pf(__expf(x));
+  return x * tanhf(sp);
+}
+__device__ __forceinline__ float act_elu(float x) { return x > 0.0f ? x : expm1f(x); }
+__device__ __forceinline__ float act_snake(float x, float alpha) {
+  float s = sinf(x * alpha);
+  return x + (1.0f / (alpha + 1e-9f)) * s * s;
+}
+__device__ __forceinline__ float apply_act(int act, float v, float param, float slope) {
+  switch (act) {
+    case CV_ACT_GELU: return act_gelu(v);
+    case CV_ACT_SILU: return act_silu(v);
+    case CV_ACT_MISH: return act_mish(v);
+    case CV_ACT_LEAKY: return v > 0.0f ? v : v * slope;
+    case CV_ACT_ELU: return act_elu(v);
+    case CV_ACT_SNAKE: return act_snake(v, param);
+    case CV_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

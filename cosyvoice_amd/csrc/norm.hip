@@ -1,0 +1,90 @@
+// cv_layernorm: row LayerNorm / RMSNorm over the last dim with fused affine, optional per-group add (time embedding),
+// optional Mish, fp32 and/or 16-bit outputs.  One wave per row (dim <= 8192), float4 loads, two-pass in registers.
+#include "cv_device.h"
+
+namespace {
+
+template <int ODT>
+__global__ __launch_bounds__(256) void norm_kernel(const cv_norm_params p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  const float* x = p.x + (int64_t)row * p.ldx;
+  constexpr int MAXV = 8;  // float4 per lane -> dim <= 64*4*8 = 2048
+  float4 v[MAXV];
+  const int nv = p.dim >> 2;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 64 + lane;
+    if (c < nv) {
+      v[i] = *(const float4*)(x + c * 4);
+      s += v[i].x + v[i].y + v[i].z + v[i].w;
+    } else {
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  float mean = 0.f;
+  if (!p.rms) mean = wave_sum(s) / (float)p.dim;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 64 + lane;
+    if (c < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += a * a + b * b + cc * cc + d * d;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)p.dim + p.eps);
+  const float* add = p.add ? p.add + (int64_t)(row / p.rows_per_group) * p.add_ld : nullptr;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 64 + lane;
+    if (c >= nv) continue;
+    const int col = c * 4;
+    float o[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float y = (o[r] - mean) * rstd;
+      if (p.gamma) y *= p.gamma[col + r];
+      if (p.beta) y += p.beta[col + r];
+      if (p.act == CV_ACT_MISH) y = act_mish(y);
+      if (add) y += add[col + r];
+      o[r] = y * p.out_scale;
+    }
+    if (p.out_f32) *(float4*)(p.out_f32 + (int64_t)row * p.ldo32 + col) = make_float4(o[0], o[1], o[2], o[3]);
+    if (p.out_act) {
+      if constexpr (ODT == CV_F32) {
+        *(float4*)((float*)p.out_act + (int64_t)row * p.ldoa + col) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+        uint2 u;
+        u.x = pack2<ODT>(o[0], o[1]);
+        u.y = pack2<ODT>(o[2], o[3]);
+        *(uint2*)((uint16_t*)p.out_act + (int64_t)row * p.ldoa + col) = u;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int cv_layernorm(const cv_norm_params* pp, void* stream) {
+  if (!pp) return CV_ERR_ARG;
+  cv_norm_params p = *pp;
+  if (p.rows <= 0 || p.dim <= 0 || (p.dim & 3) || p.dim > 2048 || !p.x) return CV_ERR_ARG;
+  if ((p.ldx & 3) || (!p.out_f32 && !p.out_act)) return CV_ERR_ARG;
+  if (p.out_f32 && (p.ldo32 & 3)) return CV_ERR_ARG;
+  if (p.out_act && (p.ldoa & 3)) return CV_ERR_ARG;
+  if (p.out_scale == 0.f) p.out_scale = 1.f;
+  if (p.rows_per_group <= 0) p.rows_per_group = p.rows;
+  dim3 grid((p.rows + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  switch (p.out_dtype) {
+    case CV_F32: hipLaunchKernelGGL(norm_kernel<CV_F32>, grid, dim3(256), 0, st, p); break;
+    case CV_BF16: hipLaunchKernelGGL(norm_kernel<CV_BF16>, grid, dim3(256), 0, st, p); break;
+    case CV_F16: hipLaunchKernelGGL(norm_kernel<CV_F16>, grid, dim3(256), 0, st, p); break;
+    default: return CV_ERR_ARG;
+  }
+  CV_CHECK_LAUNCH();
+  return CV_OK;
+}

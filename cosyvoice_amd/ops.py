@@ -1,0 +1,99 @@
+"""Thin tensor-level wrappers over the C ABI (device pointers out of torch tensors; torch is plumbing only)."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import (ACT_ELU, ACT_GELU, ACT_LEAKY, ACT_MISH, ACT_NONE, ACT_SILU, ACT_SNAKE, ACT_SWIGLU, ACT_TANH,  # noqa: F401
+                   CV_BF16, CV_F16, CV_F32, OUT_QKV, OUT_ROWMAJOR)
+
+
+def _req_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("cosyvoice_amd ops need device tensors (no CPU path)")
+
+
+def gemm(A, W, M, N, K, *, dtype=None, batch=1, batch_inner=0, a_bs=(0, 0), lda=None, a_rows=0, cin=0,
+         a_row_stride=1, tap_base=0, tap_step=0, w_bs=(0, 0), ldw=None, bias=None, res=None, res_bs=(0, 0), ldres=0,
+         res2=None, ldres2=0, out_scale=1.0, act=ACT_NONE, act_param=None, act_slope=0.0, out_f32=None, o32_bs=(0, 0),
+         ldo32=0, out_act=None, oa_bs=(0, 0), ldoa=0, out_row_stride=1, out_row_off=0, out_rows=0, qkv=None):
+    _req_cuda(A, W, bias, res, res2, out_f32, out_act)
+    p = L.GemmParams()
+    p.dtype = L.TORCH_DT[A.dtype] if dtype is None else dtype
+    p.M, p.N, p.K, p.batch, p.batch_inner = M, N, K, batch, batch_inner
+    p.A, p.a_bs0, p.a_bs1, p.lda, p.a_rows = A.data_ptr(), a_bs[0], a_bs[1], (lda if lda is not None else A.stride(-2)), a_rows
+    p.cin, p.a_row_stride, p.tap_base, p.tap_step = cin, a_row_stride, tap_base, tap_step
+    p.W, p.w_bs0, p.w_bs1, p.ldw = W.data_ptr(), w_bs[0], w_bs[1], (ldw if ldw is not None else W.stride(-2))
+    p.bias = L.ptr(bias)
+    p.res, p.res_bs0, p.res_bs1, p.ldres = L.ptr(res), res_bs[0], res_bs[1], ldres
+    p.res2, p.ldres2 = L.ptr(res2), ldres2
+    p.out_scale, p.act, p.act_param, p.act_slope = out_scale, act, L.ptr(act_param), act_slope
+    p.out_f32, p.o32_bs0, p.o32_bs1, p.ldo32 = L.ptr(out_f32), o32_bs[0], o32_bs[1], ldo32
+    p.out_act, p.oa_bs0, p.oa_bs1, p.ldoa = L.ptr(out_act), oa_bs[0], oa_bs[1], ldoa
+    p.out_row_stride, p.out_row_off, p.out_rows = out_row_stride, out_row_off, out_rows
+    if qkv is not None:
+        p.out_mode = OUT_QKV
+        p.q_cols, p.k_cols, p.q_scale = qkv["q_cols"], qkv["k_cols"], qkv.get("q_scale", 1.0)
+        p.k_out, p.k_bs, p.ldk = qkv["k_out"].data_ptr(), qkv["k_bs"], qkv["ldk"]
+        p.vt_out, p.vt_heads, p.vt_ld = qkv["vt_out"].data_ptr(), qkv["vt_heads"], qkv["vt_ld"]
+    L.check(L.lib().cv_gemm(C.byref(p), L.stream_ptr()), "cv_gemm")
+
+
+def linear(x, W, *, bias=None, res=None, act=ACT_NONE, act_param=None, act_slope=0.0, out_f32=None, out_act=None,
+           out_scale=1.0):
+    """x (rows, K) contiguous rows (stride(0) = ld); W (N, K)."""
+    M, K = x.shape
+    N = W.shape[0]
+    gemm(x, W, M, N, K, bias=bias, res=res, ldres=(res.stride(0) if res is not None else 0), act=act,
+         act_param=act_param, act_slope=act_slope, out_f32=out_f32, ldo32=(out_f32.stride(0) if out_f32 is not None else 0),
+         out_act=out_act, ldoa=(out_act.stride(0) if out_act is not None else 0), out_scale=out_scale)
+
+
+def conv1d_cl(x, Wp, taps, *, dilation=1, pad_left=0, stride=1, T_out=None, **kw):
+    """Channels-last conv: x (B, T, Cin) -> (B, T_out, Cout); Wp (Cout, taps*Cin) with k = tap*Cin + ci.
+    kw: bias/res/act/... as gemm, with out tensors shaped (B, T_out, Cout)."""
+    B, T, Cin = x.shape
+    N = Wp.shape[0]
+    if T_out is None:
+        T_out = T
+    out_f32, out_act, res, res2 = kw.pop("out_f32", None), kw.pop("out_act", None), kw.pop("res", None), kw.pop("res2", None)
+    gemm(x, Wp, T_out, N, taps * Cin, batch=B, a_bs=(x.stride(0), 0), lda=x.stride(1), a_rows=T, cin=Cin,
+         a_row_stride=stride, tap_base=-pad_left, tap_step=dilation,
+         res=res, res_bs=((res.stride(0), 0) if res is not None else (0, 0)), ldres=(res.stride(1) if res is not None else 0),
+         res2=res2, ldres2=(res2.stride(1) if res2 is not None else 0),
+         out_f32=out_f32, o32_bs=((out_f32.stride(0), 0) if out_f32 is not None else (0, 0)),
+         ldo32=(out_f32.stride(1) if out_f32 is not None else 0),
+         out_act=out_act, oa_bs=((out_act.stride(0), 0) if out_act is not None else (0, 0)),
+         ldoa=(out_act.stride(1) if out_act is not None else 0), **kw)
+
+
+def layernorm(x, gamma, beta, eps, *, rms=False, add=None, rows_per_group=0, act=ACT_NONE, out_f32=None, out_act=None,
+              out_scale=1.0):
+    """x (rows, dim) fp32."""
+    _req_cuda(x, gamma, beta, add, out_f32, out_act)
+    p = L.NormParams()
+    p.rows, p.dim, p.rms, p.eps = x.shape[0], x.shape[1], int(rms), eps
+    p.x, p.ldx = x.data_ptr(), x.stride(0)
+    p.gamma, p.beta = L.ptr(gamma), L.ptr(beta)
+    p.add, p.add_ld, p.rows_per_group = L.ptr(add), (add.stride(0) if add is not None else 0), rows_per_group
+    p.act, p.out_scale = act, out_scale
+    p.out_dtype = L.TORCH_DT[out_act.dtype] if out_act is not None else CV_F32
+    p.out_f32, p.ldo32 = L.ptr(out_f32), (out_f32.stride(0) if out_f32 is not None else 0)
+    p.out_act, p.ldoa = L.ptr(out_act), (out_act.stride(0) if out_act is not None else 0)
+    L.check(L.lib().cv_layernorm(C.byref(p), L.stream_ptr()), "cv_layernorm")
+
+
+def attention(q, k, vt, out, *, H, Hkv, Tq, Tk, scale, q_bs, ldq, k_bs, ldk, vt_ld, o_bs, ldo, B, klen=None, chunk=0,
+              causal=False, causal_off=0, bias=None, bias_bs=0, bias_hs=0, bias_ld=0):
+    _req_cuda(q, k, vt, out, klen, bias)
+    p = L.AttnParams()
+    p.dtype = L.TORCH_DT[q.dtype]
+    p.B, p.H, p.Hkv, p.Tq, p.Tk = B, H, Hkv, Tq, Tk
+    p.q, p.q_bs, p.ldq = q.data_ptr(), q_bs, ldq
+    p.k, p.k_bs, p.ldk = k.data_ptr(), k_bs, ldk
+    p.vt, p.vt_ld = vt.data_ptr(), vt_ld
+    p.out, p.o_bs, p.ldo = out.data_ptr(), o_bs, ldo
+    p.scale, p.klen, p.chunk, p.causal, p.causal_off = scale, L.ptr(klen), chunk, int(causal), causal_off
+    p.bias, p.bias_bs, p.bias_hs, p.bias_ld = L.ptr(bias), bias_bs, bias_hs, bias_ld
+    L.check(L.lib().cv_attention(C.byref(p), L.stream_ptr()), "cv_attention")

@@ -1,0 +1,113 @@
+/*
+ * cosyvoice_amd — C ABI of the MI355X (gfx950) hot-path library  libcosyvoice_amd.so
+ *
+ * The reference (duj12/CosyVoice) has no C/FFI boundary: its plug-in seam is Python
+ * duck-typing.  This header is the boundary the build adds underneath that
+ * seam.  Conventions for every entry point:
+ *   - raw device pointers (tensor.data_ptr()), caller owns every buffer and workspace;
+ *   - explicit stream (hipStream_t passed as void*); nothing is launched on another stream;
+ *   - returns 0 on success, a negative cv_status otherwise; no C++ exception crosses the ABI;
+ *   - no hidden allocation or synchronisation inside launch functions (graph-capturable);
+ *   - thread-compatible: distinct streams + workspaces may be driven concurrently.
+ *
+ * Each op names the reference code it replaces (file:line under /root/reference).
+ */
+#ifndef COSYVOICE_AMD_H
+#define COSYVOICE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { CV_OK = 0, CV_ERR_ARG = -1, CV_ERR_LAUNCH = -2, CV_ERR_UNSUPPORTED = -3 } cv_status;
+typedef enum { CV_F32 = 0, CV_BF16 = 1, CV_F16 = 2 } cv_dtype;
+typedef enum {
+  CV_ACT_NONE = 0, CV_ACT_GELU = 1, CV_ACT_SILU = 2, CV_ACT_MISH = 3, CV_ACT_LEAKY = 4,
+  CV_ACT_ELU = 5, CV_ACT_SNAKE = 6, CV_ACT_TANH = 7, CV_ACT_SWIGLU = 8
+} cv_act;
+typedef enum { CV_OUT_ROWMAJOR = 0, CV_OUT_QKV = 1 } cv_out_mode;
+
+int cv_version(void);
+const char* cv_arch(void); /* "gfx950" */
+
+/* ------------------------------------------------------------------------------------------
+ * cv_gemm — C[z][m][n] = epilogue( sum_k A[z][row(m,k)][ci(k)] * W[n][k] ), MFMA, fp32 accumulate.
+ * One kernel family for every Linear and Conv1d/ConvTranspose1d on the path (channels-last
+ * activations, implicit im2col: k = tap*cin + ci, A row = m*a_row_stride + tap_base + tap*tap_step,
+ * rows outside [0,a_rows) read as zero = the conv padding).
+ * Replaces: torch.nn.Linear / Conv1d / ConvTranspose1d calls of
+ *   cosyvoice/flow/decoder.py:36-85,222-334, flow/components/transformer.py:243-316,
+ *   transformer/attention.py:69-76, transformer/positionwise_feed_forward.py:47-56,
+ *   hifigan/generator.py:91-98,349-381, hifigan/f0_predictor.py:52-55, HF Qwen2 linears (llm/llm.py:754-766).
+ * Epilogue: v = (acc + bias[n] + res[m][n] + res2[m][n]) * out_scale; out_f32 = v; out_act = T(act(v)).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cv_gemm_params {
+  int32_t dtype;            /* cv_dtype of A, W and out_act */
+  int32_t M, N, K;          /* per-batch output rows, output cols, reduction length (= taps*cin) */
+  int32_t batch, batch_inner; /* grid.z = batch; z -> (z1 = z / batch_inner, z0 = z % batch_inner) */
+  const void* A; int64_t a_bs0, a_bs1; int32_t lda; int32_t a_rows;
+  int32_t cin, a_row_stride, tap_base, tap_step;
+  const void* W; int64_t w_bs0, w_bs1; int32_t ldw;
+  const float* bias;
+  const float* res;  int64_t res_bs0, res_bs1;  int32_t ldres;
+  const float* res2; int32_t ldres2;            /* same batch strides as res */
+  float out_scale;
+  int32_t act; const float* act_param; float act_slope;
+  float* out_f32; int64_t o32_bs0, o32_bs1; int32_t ldo32;
+  void* out_act;  int64_t oa_bs0, oa_bs1;   int32_t ldoa;
+  int32_t out_row_stride, out_row_off, out_rows; /* output row = m*out_row_stride + out_row_off, stored if in [0,out_rows) */
+  int32_t out_mode;         /* cv_out_mode */
+  /* CV_OUT_QKV: columns [0,q_cols) -> out_act (ld ldoa) scaled by q_scale; [q_cols,q_cols+k_cols) -> k_out (ld ldk);
+     the rest -> vt_out transposed: vt_out[((z*vt_heads + h)*64 + d) * vt_ld + m], head_dim 64 */
+  int32_t q_cols, k_cols; float q_scale;
+  void* k_out; int64_t k_bs; int32_t ldk;
+  void* vt_out; int32_t vt_heads, vt_ld;
+} cv_gemm_params;
+int cv_gemm(const cv_gemm_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * cv_layernorm — y = act((x - mean) * rstd * gamma + beta + add[row_group]) over the last dim;
+ * rms != 0 -> RMSNorm (no mean, no beta).  fp32 in, fp32 and/or 16-bit out.
+ * Replaces nn.LayerNorm / Qwen2RMSNorm (+ Mish of CausalBlock1D, flow/decoder.py:36-49).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cv_norm_params {
+  int32_t rows, dim; int32_t rms; float eps;
+  const float* x; int32_t ldx;
+  const float* gamma; const float* beta;
+  const float* add; int32_t add_ld; int32_t rows_per_group; /* optional per-group vector added after affine (time-embedding) */
+  int32_t act;            /* cv_act applied last (NONE or MISH) */
+  float out_scale;
+  int32_t out_dtype;      /* dtype of out_act */
+  float* out_f32; int32_t ldo32;
+  void* out_act; int32_t ldoa;
+} cv_norm_params;
+int cv_layernorm(const cv_norm_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * cv_attention — flash attention, head_dim 64, 16-bit operands, fp32 softmax/accumulate.
+ *   S[i][j] = scale * q_i . k_j + bias[i][j];  masks: j < klen[b]; chunk: j < (i/chunk+1)*chunk; causal: j <= i + causal_off
+ * Q [B][Tq][ldq] (head h at column h*64), K [B][Tk][ldk] (kv head at column hk*64),
+ * Vt [B][Hkv][64][vt_ld] (keys contiguous), out [B][Tq][ldo] 16-bit.
+ * Replaces diffusers Attention (flow/components/transformer.py:196-204), RelPositionMultiHeadedAttention
+ * (transformer/attention.py:249-330; bias = the rel-shifted matrix_bd as a strided view) and HF Qwen2 SDPA prefill.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cv_attn_params {
+  int32_t dtype; int32_t B, H, Hkv, Tq, Tk;
+  const void* q; int64_t q_bs; int32_t ldq;
+  const void* k; int64_t k_bs; int32_t ldk;
+  const void* vt; int32_t vt_ld;
+  void* out; int64_t o_bs; int32_t ldo;
+  float scale;
+  const int32_t* klen;      /* [B] or null (= Tk) */
+  int32_t chunk;            /* 0 = off */
+  int32_t causal; int32_t causal_off;
+  const float* bias; int64_t bias_bs, bias_hs; int32_t bias_ld; /* fp32 additive bias view or null */
+} cv_attn_params;
+int cv_attention(const cv_attn_params* p, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

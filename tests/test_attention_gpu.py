@@ -1,0 +1,80 @@
+"""GPU: cv_attention (flash, head_dim 64) against a plain torch fp32 softmax(QK^T)V reference."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(q, k, v, scale, klen=None, chunk=0, causal=False, causal_off=0, bias=None):
+    # q (B,H,Tq,64) k,v (B,Hkv,Tk,64) fp32
+    B, H, Tq, _ = q.shape
+    Hkv, Tk = k.shape[1], k.shape[2]
+    rep = H // Hkv
+    kk = k.repeat_interleave(rep, 1)
+    vv = v.repeat_interleave(rep, 1)
+    s = torch.matmul(q, kk.transpose(-1, -2)) * scale
+    if bias is not None:
+        s = s + bias
+    i = torch.arange(Tq, device=q.device)[:, None]
+    j = torch.arange(Tk, device=q.device)[None, :]
+    ok = torch.ones(Tq, Tk, dtype=torch.bool, device=q.device)
+    if causal:
+        ok &= j <= i + causal_off
+    if chunk:
+        ok &= j < (i // chunk + 1) * chunk
+    ok = ok[None, None].expand(B, H, Tq, Tk).clone()
+    if klen is not None:
+        ok &= (j[None, None] < klen[:, None, None, None])
+    s = s.masked_fill(~ok, float("-inf"))
+    return torch.matmul(torch.softmax(s, -1), vv)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,Hkv,Tq,Tk,mode", [
+    (2, 8, 8, 500, 500, "plain"), (2, 8, 8, 130, 130, "klen"), (1, 8, 8, 200, 200, "chunk"),
+    (2, 14, 2, 107, 107, "causal"), (1, 8, 8, 100, 100, "bias"), (1, 4, 4, 1000, 1000, "plain"),
+])
+def test_attention_vs_torch(dt, B, H, Hkv, Tq, Tk, mode):
+    from cosyvoice_amd import ops
+    torch.manual_seed(0)
+    dev = "cuda"
+    q = torch.randn(B, Tq, H * 64, device=dev).to(dt)
+    k = torch.randn(B, Tk, Hkv * 64, device=dev).to(dt)
+    v = torch.randn(B, Tk, Hkv * 64, device=dev).to(dt)
+    Tp = (Tk + 63) // 64 * 64
+    vt = torch.full((B, Hkv, 64, Tp), float("nan"), device=dev, dtype=dt)  # padding must not leak
+    vt[..., :Tk] = v.view(B, Tk, Hkv, 64).permute(0, 2, 3, 1)
+    out = torch.zeros(B, Tq, H * 64, device=dev, dtype=dt)
+    kw = {}
+    rkw = {}
+    if mode == "klen":
+        kl = torch.tensor([Tk, Tk - 37], device=dev, dtype=torch.int32)
+        kw["klen"] = kl
+        rkw["klen"] = kl
+    if mode == "chunk":
+        kw["chunk"] = 50
+        rkw["chunk"] = 50
+    if mode == "causal":
+        kw["causal"] = True
+        rkw["causal"] = True
+    bias = None
+    if mode == "bias":
+        raw = torch.randn(B, H, Tq, 2 * Tq - 1, device=dev)
+        # rel-shift view (attention.py:225-247): bias[i][j] = raw[i][Tq-1-i+j]
+        kw.update(bias=raw.view(-1)[Tq - 1:], bias_bs=H * Tq * (2 * Tq - 1), bias_hs=Tq * (2 * Tq - 1), bias_ld=2 * Tq - 2)
+        idx = (Tq - 1 - torch.arange(Tq, device=dev))[:, None] + torch.arange(Tq, device=dev)[None, :]
+        rkw["bias"] = torch.gather(raw, 3, idx[None, None].expand(B, H, Tq, Tq))
+    scale = 1.0 / math.sqrt(64)
+    ops.attention(q, k, vt, out, B=B, H=H, Hkv=Hkv, Tq=Tq, Tk=Tk, scale=scale, q_bs=Tq * H * 64, ldq=H * 64,
+                  k_bs=Tk * Hkv * 64, ldk=Hkv * 64, vt_ld=Tp, o_bs=Tq * H * 64, ldo=H * 64, **kw)
+    torch.cuda.synchronize()
+    ref = _ref(q.float().view(B, Tq, H, 64).transpose(1, 2), k.float().view(B, Tk, Hkv, 64).transpose(1, 2),
+               v.float().view(B, Tk, Hkv, 64).transpose(1, 2), scale, **rkw).transpose(1, 2).reshape(B, Tq, H * 64)
+    o = out.float()
+    if mode == "klen":  # rows of the shorter sequence beyond its length are padding
+        pass
+    assert torch.isfinite(o).all()
+    err = (o - ref).abs().max().item()
+    assert err < (3e-2 if dt == torch.bfloat16 else 4e-3), err

@@ -1,0 +1,104 @@
+"""GPU: cv_gemm / cv_layernorm through the C ABI against plain torch fp32 references of the same op."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTS = [torch.float32, torch.bfloat16, torch.float16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2, torch.float16: 3e-3}
+
+
+def _rel(a, b):
+    return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-12)).item()
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 256), (128, 1536, 256), (77, 80, 256), (2256, 4864, 896), (300, 18, 448)])
+def test_linear_epilogues(dt, M, N, K):
+    from cosyvoice_amd import ops
+    torch.manual_seed(0)
+    dev = "cuda"
+    x = torch.randn(M, K, device=dev).to(dt)
+    W = (torch.randn(N, K, device=dev) / K ** 0.5).to(dt)
+    bias = torch.randn(N, device=dev)
+    res = torch.randn(M, N, device=dev)
+    ref = x.float() @ W.float().t() + bias + res
+    o32 = torch.empty(M, N, device=dev)
+    oa = torch.empty(M, N, device=dev, dtype=dt)
+    ops.linear(x, W, bias=bias, res=res, act=ops.ACT_GELU, out_f32=o32, out_act=oa)
+    torch.cuda.synchronize()
+    assert _rel(o32, ref) < TOL[dt] * 0.5 + 1e-6
+    assert _rel(oa, F.gelu(ref)) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("Cin,Cout,k,dil,T", [(256, 256, 3, 1, 500), (64, 64, 11, 5, 3000), (320, 256, 3, 1, 333), (96, 512, 7, 1, 200)])
+def test_conv1d_channels_last(dt, Cin, Cout, k, dil, T):
+    from cosyvoice_amd import ops
+    torch.manual_seed(1)
+    dev = "cuda"
+    B = 2
+    x = torch.randn(B, T, Cin, device=dev).to(dt)
+    w = (torch.randn(Cout, Cin, k, device=dev) / (Cin * k) ** 0.5).to(dt)
+    bias = torch.randn(Cout, device=dev)
+    alpha = torch.rand(Cout, device=dev) + 0.5
+    pad = (k * dil - dil) // 2
+    ref = F.conv1d(x.float().transpose(1, 2), w.float(), bias, dilation=dil, padding=pad).transpose(1, 2)
+    Wp = w.permute(0, 2, 1).reshape(Cout, k * Cin).contiguous()
+    o32 = torch.empty(B, T, Cout, device=dev)
+    oa = torch.empty(B, T, Cout, device=dev, dtype=dt)
+    ops.conv1d_cl(x, Wp, k, dilation=dil, pad_left=pad, bias=bias, act=ops.ACT_SNAKE, act_param=alpha, out_f32=o32, out_act=oa)
+    torch.cuda.synchronize()
+    assert _rel(o32, ref) < TOL[dt] * 0.5 + 1e-6
+    sn = ref + (1.0 / (alpha + 1e-9)) * torch.sin(ref * alpha) ** 2
+    assert _rel(oa, sn) < TOL[dt]
+    # causal variant (left pad k-1), as CausalConv1d flow/decoder.py:59-85
+    refc = F.conv1d(F.pad(x.float().transpose(1, 2), ((k - 1) * dil, 0)), w.float(), bias, dilation=dil).transpose(1, 2)
+    ops.conv1d_cl(x, Wp, k, dilation=dil, pad_left=(k - 1) * dil, bias=bias, out_f32=o32)
+    torch.cuda.synchronize()
+    assert _rel(o32, refc) < TOL[dt] * 0.5 + 1e-6
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_qkv_split_mode(dt):
+    from cosyvoice_amd import ops
+    torch.manual_seed(2)
+    dev = "cuda"
+    B, T, C, H = 2, 200, 256, 8
+    Tp = 208
+    x = torch.randn(B, T, C, device=dev).to(dt)
+    W = (torch.randn(3 * H * 64, C, device=dev) / C ** 0.5).to(dt)
+    q = torch.zeros(B, T, H * 64, device=dev, dtype=dt)
+    k = torch.zeros(B, T, H * 64, device=dev, dtype=dt)
+    vt = torch.zeros(B, H, 64, Tp, device=dev, dtype=dt)
+    ops.gemm(x, W, T, 3 * H * 64, C, batch=B, a_bs=(T * C, 0), lda=C, out_act=q, oa_bs=(T * H * 64, 0), ldoa=H * 64,
+             qkv=dict(q_cols=H * 64, k_cols=H * 64, q_scale=0.125, k_out=k, k_bs=T * H * 64, ldk=H * 64, vt_out=vt,
+                      vt_heads=H, vt_ld=Tp))
+    torch.cuda.synchronize()
+    ref = x.float() @ W.float().t()
+    assert _rel(q, ref[..., :512] * 0.125) < TOL[dt]
+    assert _rel(k, ref[..., 512:1024]) < TOL[dt]
+    vref = ref[..., 1024:].reshape(B, T, H, 64).permute(0, 2, 3, 1)
+    assert _rel(vt[..., :T], vref) < TOL[dt]
+
+
+@pytest.mark.parametrize("odt", DTS)
+@pytest.mark.parametrize("rows,dim,rms", [(1000, 256, False), (37, 512, False), (16, 896, True)])
+def test_layernorm(odt, rows, dim, rms):
+    from cosyvoice_amd import ops
+    torch.manual_seed(3)
+    dev = "cuda"
+    x = torch.randn(rows, dim, device=dev) * 3 + 1
+    g = torch.randn(dim, device=dev)
+    b = None if rms else torch.randn(dim, device=dev)
+    if rms:
+        ref = g * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6))
+    else:
+        ref = F.layer_norm(x, (dim,), g, b, 1e-5)
+    o32 = torch.empty(rows, dim, device=dev)
+    oa = torch.empty(rows, dim, device=dev, dtype=odt)
+    ops.layernorm(x, g, b, 1e-6 if rms else 1e-5, rms=rms, out_f32=o32, out_act=oa)
+    torch.cuda.synchronize()
+    assert (o32 - ref).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-5
+    assert _rel(oa, ref) < {torch.float32: 1e-6, torch.bfloat16: 5e-3, torch.float16: 6e-4}[odt]
