@@ -1,0 +1,299 @@
+"""HiFT vocoder on MI355X — host side of the drop-in for the reference's ``HiFTGenerator``
+(/root/reference/cosyvoice/hifigan/generator.py:223-411) and ``ConvRNNF0Predictor``
+(hifigan/f0_predictor.py:19-55).  Same constructor hyper-parameters (via HiftConfig), same
+``load_state_dict`` key names (legacy weight-norm ``weight_g/weight_v`` folded at load,
+SURVEY.md §8b (i)), same ``inference(speech_feat, cache_source) -> (wav (B,S), source (B,1,S))``
+and ``decode(x, s)`` signatures.  All arithmetic runs in libcosyvoice_amd.so (HIP, gfx950):
+channels-last activations, every Conv1d / ConvTranspose1d as an implicit-GEMM MFMA launch with
+the Snake / leaky-relu / residual / 1/3-mean fused into the epilogues.
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .config import HiftConfig
+from .weights import fold_weight_norm, hift_downsample_plan
+
+
+def _get_padding(k, d=1):
+    return int((k * d - d) / 2)
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class _Conv:
+    """Packed Conv1d: W' [Cout][tap*Cin_pad + ci]."""
+
+    def __init__(self, w, b, dtype, device, dilation=1, pad_left=0, stride=1):
+        cout, cin, k = w.shape
+        ch = 4 if dtype == torch.float32 else 8
+        self.cin_pad = _round_up(cin, ch)
+        wp = torch.zeros(cout, k, self.cin_pad, dtype=torch.float32)
+        wp[:, :, :cin] = w.permute(0, 2, 1)
+        self.w = wp.reshape(cout, k * self.cin_pad).to(device=device, dtype=dtype).contiguous()
+        self.b = b.to(device=device, dtype=torch.float32).contiguous() if b is not None else None
+        self.k, self.cout, self.dilation, self.pad_left, self.stride = k, cout, dilation, pad_left, stride
+
+
+class _ConvT:
+    """ConvTranspose1d(stride u, kernel k, padding p) as u phase GEMMs:
+    out[q*u + r] = sum_m x[q + c_r - m] . w[:, :, j0_r + m*u],  j0_r = (r+p) % u, c_r = (r+p) // u."""
+
+    def __init__(self, w, b, u, p, dtype, device):
+        cin, cout, k = w.shape
+        self.u, self.cout, self.cin = u, cout, cin
+        self.b = b.to(device=device, dtype=torch.float32).contiguous()
+        self.phases = []
+        for r in range(u):
+            j0, c = (r + p) % u, (r + p) // u
+            taps = list(range(j0, k, u))
+            wp = torch.stack([w[:, :, j].t() for j in taps], dim=1)  # (cout, ntaps, cin)
+            self.phases.append((wp.reshape(cout, len(taps) * cin).to(device=device, dtype=dtype).contiguous(), len(taps), c))
+
+
+class HiFTGenerator:
+    def __init__(self, cfg: Optional[HiftConfig] = None, dtype: torch.dtype = torch.float32, device: str = "cuda"):
+        self.cfg = cfg or HiftConfig.v2()
+        self.dtype = dtype
+        self.device = torch.device(device)
+        self.num_kernels = len(self.cfg.resblock_kernel_sizes)
+        self.num_upsamples = len(self.cfg.upsample_rates)
+        self._loaded = False
+        self._ws: Dict[tuple, dict] = {}
+
+    # -- torch.nn.Module-like surface used by cli/model.py:72-81
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    def load_state_dict(self, sd, strict: bool = False):
+        sd = {k.replace("generator.", ""): v.detach().to("cpu", torch.float32) for k, v in sd.items()}  # model.py:79
+        cfg, dt, dev = self.cfg, self.dtype, self.device
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+
+        def conv(name, **kw):
+            return _Conv(fold_weight_norm(sd, name), sd[f"{name}.bias"], dt, dev, **kw)
+
+        def resblock(name, k, dils):
+            rb = []
+            for j, d in enumerate(dils):
+                rb.append(dict(c1=conv(f"{name}.convs1.{j}", dilation=d, pad_left=_get_padding(k, d)),
+                               c2=conv(f"{name}.convs2.{j}", dilation=1, pad_left=_get_padding(k, 1)),
+                               a1=f32(sd[f"{name}.activations1.{j}.alpha"]), a2=f32(sd[f"{name}.activations2.{j}.alpha"])))
+            return rb
+
+        self.conv_pre = conv("conv_pre", pad_left=3)
+        self.ups = [_ConvT(fold_weight_norm(sd, f"ups.{i}"), sd[f"ups.{i}.bias"], u, (k - u) // 2, dt, dev)
+                    for i, (u, k) in enumerate(zip(cfg.upsample_rates, cfg.upsample_kernel_sizes))]
+        self.source_downs, self.source_resblocks = [], []
+        for i, (stride, ks, pad) in enumerate(hift_downsample_plan(cfg)):
+            self.source_downs.append(_Conv(sd[f"source_downs.{i}.weight"], sd[f"source_downs.{i}.bias"], dt, dev,
+                                           pad_left=pad, stride=stride))
+            self.source_resblocks.append(resblock(f"source_resblocks.{i}", cfg.source_resblock_kernel_sizes[i],
+                                                  cfg.source_resblock_dilation_sizes[i]))
+        self.resblocks = []
+        for i in range(self.num_upsamples):
+            for j in range(self.num_kernels):
+                self.resblocks.append(resblock(f"resblocks.{i * self.num_kernels + j}", cfg.resblock_kernel_sizes[j],
+                                               cfg.resblock_dilation_sizes[j]))
+        self.conv_post = conv("conv_post", pad_left=3)
+        self.f0_convs = [conv(f"f0_predictor.condnet.{idx}", pad_left=1) for idx in (0, 2, 4, 6, 8)]
+        ch = 4 if dt == torch.float32 else 8
+        fc = cfg.f0_cond_channels
+        wcls = torch.zeros(4, fc)  # N padded to 4 so the vector epilogue applies; row 0 is the classifier
+        wcls[0] = sd["f0_predictor.classifier.weight"][0]
+        self.f0_cls_w = wcls.to(device=dev, dtype=dt).contiguous()
+        bcls = torch.zeros(4)
+        bcls[0] = sd["f0_predictor.classifier.bias"][0]
+        self.f0_cls_b = f32(bcls)
+        self.lin_w = f32(sd["m_source.l_linear.weight"].reshape(-1))
+        self.lin_b = f32(sd["m_source.l_linear.bias"].reshape(-1))
+        self._stft_ld = _round_up(cfg.n_fft + 2, ch)
+        self._loaded = True
+        return self
+
+    # ------------------------------------------------------------------ workspaces (no allocation in steady state)
+    def _workspace(self, B, T):
+        key = (B, T)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        cfg, dt, dev = self.cfg, self.dtype, self.device
+        e = lambda *shape, dtype=torch.float32: torch.empty(*shape, device=dev, dtype=dtype)
+        ws = {}
+        S = T * cfg.total_upsample
+        F = S // cfg.hop_len + 1
+        ws["mel_cl"] = e(B, T, self.conv_pre.cin_pad, dtype=dt)
+        ws["stft"] = e(B, F, self._stft_ld, dtype=dt)
+        ws["a_pre"] = e(B, T, cfg.base_channels, dtype=dt)
+        lens, chans = [], []
+        t = T
+        for i, u in enumerate(cfg.upsample_rates):
+            t = t * u + (1 if i == self.num_upsamples - 1 else 0)
+            lens.append(t)
+            chans.append(cfg.base_channels // 2 ** (i + 1))
+        ws["lens"], ws["chans"] = lens, chans
+        for i, (t, c) in enumerate(zip(lens, chans)):
+            ws[f"x{i}"] = e(B, t, c)           # stage input (ups + source), fp32 residual stream
+            ws[f"xa{i}"] = [e(B, t, c, dtype=dt) for _ in range(self.num_kernels)]  # snake'd copies per resblock
+            ws[f"r{i}"] = [e(B, t, c), e(B, t, c)]  # resblock residual ping-pong
+            ws[f"ta{i}"] = e(B, t, c, dtype=dt)   # conv1 -> snake -> conv2 intermediate
+            ws[f"ra{i}"] = e(B, t, c, dtype=dt)   # activated residual for the next conv1
+            ws[f"acc{i}"] = [e(B, t, c), e(B, t, c)]  # running sum over the parallel resblocks
+            ws[f"si{i}"] = [e(B, t, c), e(B, t, c)]   # source branch
+            ws[f"out{i}"] = e(B, t, c, dtype=dt)      # leaky-relu'd stage output feeding the next layer
+        ws["post"] = e(B, lens[-1], self._stft_ld)
+        ws["wav"] = e(B, (lens[-1] - 1) * cfg.hop_len)
+        # f0 predictor / source
+        fc = cfg.f0_cond_channels
+        ws["f0_a"] = [e(B, T, fc, dtype=dt), e(B, T, fc, dtype=dt)]
+        ws["f0_y"] = e(B, T, 4)
+        ws["f0"] = e(B, T)
+        ws["src_work"] = torch.empty(B, cfg.nb_harmonics + 1, T, device=dev, dtype=torch.float64)
+        ws["s"] = e(B, S)
+        self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ building blocks
+    def _conv(self, c: _Conv, x, T_out=None, **kw):
+        ops.conv1d_cl(x, c.w, c.k, dilation=c.dilation, pad_left=c.pad_left, stride=c.stride, T_out=T_out, bias=c.b, **kw)
+
+    def _resblock(self, rb, x32, xa, ws, i, final):
+        """x32: fp32 block input; xa: snake_{a1[0]}(x32) in dtype.  ``final`` = kwargs of the last conv2's epilogue
+        (out_f32 / out_act / res2 / out_scale / act ...).  generator.py:91-98."""
+        r, ta, ra = ws[f"r{i}"], ws[f"ta{i}"], ws[f"ra{i}"]
+        cur32, cur_a = x32, xa
+        n = len(rb)
+        for j, blk in enumerate(rb):
+            self._conv(blk["c1"], cur_a, act=ops.ACT_SNAKE, act_param=blk["a2"], out_act=ta)
+            if j < n - 1:
+                nxt = r[j & 1]
+                self._conv(blk["c2"], ta, res=cur32, out_f32=nxt, act=ops.ACT_SNAKE, act_param=rb[j + 1]["a1"], out_act=ra)
+                cur32, cur_a = nxt, ra
+            else:
+                self._conv(blk["c2"], ta, res=cur32, **final)
+
+    # ------------------------------------------------------------------ public API
+    @torch.no_grad()
+    def f0_predictor(self, speech_feat: torch.Tensor) -> torch.Tensor:
+        """speech_feat (B,80,T) fp32 -> f0 (B,T).  f0_predictor.py:52-55."""
+        assert self._loaded
+        B, _, T = speech_feat.shape
+        ws = self._workspace(B, T)
+        x = speech_feat.to(self.device, torch.float32).contiguous()
+        ops.to_channels_last(x, ws["mel_cl"])
+        self._f0_from_cl(ws, B, T)
+        return ws["f0"]
+
+    def _f0_from_cl(self, ws, B, T):
+        cur = ws["mel_cl"]
+        for n, c in enumerate(self.f0_convs):
+            out = ws["f0_a"][n & 1]
+            self._conv(c, cur, act=ops.ACT_ELU, out_act=out)
+            cur = out
+        fc = self.cfg.f0_cond_channels
+        ops.gemm(cur, self.f0_cls_w, B * T, 4, fc, lda=fc, bias=self.f0_cls_b, out_f32=ws["f0_y"], ldo32=4)
+        torch.abs(ws["f0_y"][:, :, 0], out=ws["f0"])  # |.| of one column: data-movement-class torch op
+
+    @torch.no_grad()
+    def decode(self, x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+        """x (B,80,T) mel, s (B,1,T*up) source -> wav (B, T*up).  generator.py:349-381."""
+        assert self._loaded
+        B, _, T = x.shape
+        ws = self._workspace(B, T)
+        ops.to_channels_last(x.to(self.device, torch.float32).contiguous(), ws["mel_cl"])
+        s2 = s.to(self.device, torch.float32).reshape(B, -1).contiguous()
+        return self._decode_cl(ws, B, T, s2)
+
+    def _decode_cl(self, ws, B, T, s2):
+        cfg = self.cfg
+        ops.stft16(s2, ws["stft"])
+        self._conv(self.conv_pre, ws["mel_cl"], act=ops.ACT_LEAKY, act_slope=cfg.lrelu_slope, out_act=ws["a_pre"])
+        cur_a = ws["a_pre"]
+        t_in = T
+        nk = self.num_kernels
+        for i in range(self.num_upsamples):
+            t_out, c = ws["lens"][i], ws["chans"][i]
+            last = i == self.num_upsamples - 1
+            # source branch: strided conv of the source STFT, then its ResBlock (generator.py:361-363)
+            sd_, srb = self.source_downs[i], self.source_resblocks[i]
+            si0, si1 = ws[f"si{i}"]
+            xa_src = ws[f"xa{i}"][0]  # free here: the main resblocks have not started
+            self._conv(sd_, ws["stft"], T_out=t_out, out_f32=si0, act=ops.ACT_SNAKE, act_param=srb[0]["a1"], out_act=xa_src)
+            self._resblock(srb, si0, xa_src, ws, i, dict(out_f32=si1))
+            # ups[i] (+ reflect pad on the last stage) + source fusion: x = ups(x) + si  (generator.py:355-364)
+            up = self.ups[i]
+            x32 = ws[f"x{i}"]
+            off = 1 if last else 0
+            for r, (wp, ntaps, cr) in enumerate(up.phases):
+                ops.gemm(cur_a, wp, t_in, c, ntaps * up.cin, batch=B, a_bs=(cur_a.stride(0), 0), lda=cur_a.stride(1),
+                         a_rows=t_in, cin=up.cin, tap_base=cr, tap_step=-1, bias=up.b, res=si1,
+                         res_bs=(si1.stride(0), 0), ldres=c, out_f32=x32, o32_bs=(x32.stride(0), 0), ldo32=c,
+                         out_row_stride=up.u, out_row_off=r + off, out_rows=t_out)
+            if last:
+                # ReflectionPad1d((1,0)): padded[0] = ups_out[1] = phase r=1, q=0
+                wp, ntaps, cr = up.phases[1]
+                ops.gemm(cur_a, wp, 1, c, ntaps * up.cin, batch=B, a_bs=(cur_a.stride(0), 0), lda=cur_a.stride(1),
+                         a_rows=t_in, cin=up.cin, tap_base=cr, tap_step=-1, bias=up.b, res=si1,
+                         res_bs=(si1.stride(0), 0), ldres=c, out_f32=x32, o32_bs=(x32.stride(0), 0), ldo32=c,
+                         out_row_stride=up.u, out_row_off=0, out_rows=t_out)
+            # parallel ResBlocks, mean over kernels (generator.py:366-372)
+            rbs = self.resblocks[i * nk:(i + 1) * nk]
+            xas = ws[f"xa{i}"]
+            ops.snake_multi(x32.view(B * t_out, c), [rb[0]["a1"] for rb in rbs], [a.view(B * t_out, c) for a in xas])
+            acc = ws[f"acc{i}"]
+            slope = 0.01 if last else cfg.lrelu_slope  # F.leaky_relu default after the loop (generator.py:374)
+            for j, rb in enumerate(rbs):
+                if j < nk - 1:
+                    fin = dict(out_f32=acc[j & 1])
+                    if j > 0:
+                        fin["res2"] = acc[(j - 1) & 1]
+                else:
+                    fin = dict(out_scale=1.0 / nk, act=ops.ACT_LEAKY, act_slope=slope, out_act=ws[f"out{i}"])
+                    if j > 0:
+                        fin["res2"] = acc[(j - 1) & 1]
+                self._resblock(rb, x32, xas[j], ws, i, fin)
+            cur_a = ws[f"out{i}"]
+            t_in = t_out
+        self._conv(self.conv_post, cur_a, out_f32=ws["post"])
+        ops.istft16(ws["post"], ws["wav"], cfg.audio_limit)
+        return ws["wav"]
+
+    @torch.no_grad()
+    def source(self, f0: torch.Tensor, phase_vec: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
+        """f0 (B,T) -> s (B, T*up).  Randoms are drawn on the device when not injected (generator.py:149-163)."""
+        B, T = f0.shape
+        cfg = self.cfg
+        ws = self._workspace(B, T)
+        S = T * cfg.total_upsample
+        nh = cfg.nb_harmonics + 1
+        if phase_vec is None:
+            phase_vec = (torch.rand(B, nh, device=self.device) * 2 - 1) * math.pi
+        if noise is None:
+            noise = torch.randn(B, nh, S, device=self.device)
+        phase_vec = phase_vec.to(self.device, torch.float32).reshape(B, nh).contiguous()
+        noise = noise.to(self.device, torch.float32).reshape(B, nh, S).contiguous()
+        ops.hift_source(f0.contiguous(), phase_vec, noise, self.lin_w, self.lin_b, ws["src_work"], ws["s"],
+                        cfg.total_upsample, float(cfg.sampling_rate), cfg.nsf_alpha, cfg.nsf_sigma, cfg.nsf_voiced_threshold)
+        return ws["s"]
+
+    @torch.no_grad()
+    def inference(self, speech_feat: torch.Tensor, cache_source: torch.Tensor = torch.zeros(1, 1, 0),
+                  phase_vec=None, noise=None):
+        """generator.py:399-411 -> (generated_speech (B,S), s (B,1,S))."""
+        assert self._loaded
+        B, _, T = speech_feat.shape
+        ws = self._workspace(B, T)
+        ops.to_channels_last(speech_feat.to(self.device, torch.float32).contiguous(), ws["mel_cl"])
+        self._f0_from_cl(ws, B, T)
+        s = self.source(ws["f0"], phase_vec, noise)
+        if cache_source.shape[2] != 0:
+            s[:, :cache_source.shape[2]] = cache_source.to(self.device, torch.float32).reshape(B, -1)
+        wav = self._decode_cl(ws, B, T, s)
+        return wav, s.unsqueeze(1)

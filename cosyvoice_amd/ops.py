@@ -97,3 +97,55 @@ def attention(q, k, vt, out, *, H, Hkv, Tq, Tk, scale, q_bs, ldq, k_bs, ldk, vt_
     p.scale, p.klen, p.chunk, p.causal, p.causal_off = scale, L.ptr(klen), chunk, int(causal), causal_off
     p.bias, p.bias_bs, p.bias_hs, p.bias_ld = L.ptr(bias), bias_bs, bias_hs, bias_ld
     L.check(L.lib().cv_attention(C.byref(p), L.stream_ptr()), "cv_attention")
+
+
+# ----------------------------------------------------------------------------- layout / HiFT helpers
+def to_channels_last(x, out):
+    """x (B,C,T) fp32 -> out (B,T,ld) any dtype, zero-filled pad columns."""
+    _req_cuda(x, out)
+    B, Cc, T = x.shape
+    L.check(L.lib().cv_to_channels_last(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), L.TORCH_DT[out.dtype], B, Cc, T,
+                                        out.stride(1), L.stream_ptr()), "cv_to_channels_last")
+
+
+def to_channels_first(x, out, Cc=None):
+    """x (B,T,ld) fp32 -> out (B,C,T) fp32."""
+    _req_cuda(x, out)
+    B, T, _ = x.shape
+    Cc = out.shape[1] if Cc is None else Cc
+    L.check(L.lib().cv_to_channels_first(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), B, Cc, T, x.stride(1),
+                                         L.stream_ptr()), "cv_to_channels_first")
+
+
+def snake_multi(x2d, alphas, outs):
+    """x2d (rows, C) fp32; alphas: list of (C,) fp32; outs: list of (rows, C) tensors of one dtype."""
+    _req_cuda(x2d, *alphas, *outs)
+    n = len(alphas)
+    a = (C.c_void_p * n)(*[t.data_ptr() for t in alphas])
+    o = (C.c_void_p * n)(*[t.data_ptr() for t in outs])
+    L.check(L.lib().cv_snake_multi(C.c_void_p(x2d.data_ptr()), x2d.shape[0], x2d.shape[1], x2d.stride(0), n, a, o,
+                                   outs[0].stride(0), L.TORCH_DT[outs[0].dtype], L.stream_ptr()), "cv_snake_multi")
+
+
+def stft16(s, out):
+    """s (B,S) fp32 -> out (B, S/4+1, ld>=18)."""
+    _req_cuda(s, out)
+    L.check(L.lib().cv_stft16(C.c_void_p(s.data_ptr()), C.c_void_p(out.data_ptr()), L.TORCH_DT[out.dtype], s.shape[0], s.shape[1],
+                              out.stride(1), L.stream_ptr()), "cv_stft16")
+
+
+def istft16(y, wav, audio_limit):
+    """y (B,F,ld>=18) fp32 -> wav (B,(F-1)*4) fp32."""
+    _req_cuda(y, wav)
+    L.check(L.lib().cv_istft16(C.c_void_p(y.data_ptr()), C.c_void_p(wav.data_ptr()), y.shape[0], y.shape[1], y.stride(1),
+                               C.c_float(audio_limit), L.stream_ptr()), "cv_istft16")
+
+
+def hift_source(f0, phase_vec, noise, lin_w, lin_b, work, s, up, sampling_rate, sine_amp, noise_std, vthr):
+    _req_cuda(f0, phase_vec, noise, lin_w, lin_b, work, s)
+    B, T = f0.shape
+    nh = phase_vec.shape[1]
+    L.check(L.lib().cv_hift_source(C.c_void_p(f0.data_ptr()), C.c_void_p(phase_vec.data_ptr()), C.c_void_p(noise.data_ptr()),
+                                   C.c_void_p(lin_w.data_ptr()), C.c_void_p(lin_b.data_ptr()), C.c_void_p(work.data_ptr()),
+                                   C.c_void_p(s.data_ptr()), B, T, up, nh, C.c_float(sampling_rate), C.c_float(sine_amp),
+                                   C.c_float(noise_std), C.c_float(vthr), L.stream_ptr()), "cv_hift_source")

@@ -107,6 +107,58 @@ typedef struct cv_attn_params {
 } cv_attn_params;
 int cv_attention(const cv_attn_params* p, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Layout / elementwise helpers (HBM-bound, coalesced, fp32 math).
+ * ------------------------------------------------------------------------------------------ */
+/* x [B][C][T] fp32 (the reference's channel-first tensors) -> out [B][T][ldo] of `dtype` (channels-last; columns
+ * [C,ldo) zero-filled).  Replaces the implicit layout of torch Conv1d inputs (generator.py:353, f0_predictor.py:53). */
+int cv_to_channels_last(const float* x, void* out, int32_t dtype, int32_t B, int32_t C, int32_t T, int32_t ldo, void* stream);
+/* x [B][T][ldx] fp32 -> out [B][C][T] fp32 */
+int cv_to_channels_first(const float* x, float* out, int32_t B, int32_t C, int32_t T, int32_t ldx, void* stream);
+/* Snake x + sin^2(a x)/(a+1e-9) (transformer/activation.py:73-84) of x [rows][C] fp32 with up to 4 alpha vectors,
+ * one `dtype` output per alpha: the first activation of the parallel ResBlocks (generator.py:366-372). */
+int cv_snake_multi(const float* x, int32_t rows, int32_t C, int32_t ldx, int32_t n, const float* const* alpha,
+                   void* const* out, int32_t ldo, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * HiFT source / (i)STFT kernels, n_fft 16, hop 4, periodic hann, center=True (generator.py:333-347).
+ * ------------------------------------------------------------------------------------------ */
+/* s [B][S] fp32 -> out [B][S/4+1][ldo] `dtype`: columns 0..8 real, 9..17 imag, [18,ldo) zero (torch.stft, reflect pad) */
+int cv_stft16(const float* s, void* out, int32_t dtype, int32_t B, int32_t S, int32_t ldo, void* stream);
+/* y [B][F][ldy] fp32 (conv_post output: 9 log-magnitudes, 9 phase pre-activations) -> wav [B][(F-1)*4]:
+ * mag = min(exp(y),100), phase = sin(y), iSTFT with window-envelope normalisation, clamp +-audio_limit (generator.py:376-381) */
+int cv_istft16(const float* y, float* wav, int32_t B, int32_t F, int32_t ldy, float audio_limit, void* stream);
+/* SourceModuleHnNSF (generator.py:137-220): f0 [B][T] (Hz, >=0) -> s [B][T*up]; harmonics nh (<=16);
+ * phase_vec [B][nh] (row 0 ignored = 0), noise [B][nh][T*up] standard normal, lin_w [nh], lin_b [1];
+ * work [B][nh][T] doubles (frame-start phases).  The phase scan is done per frame in fp64 (exact value of the
+ * reference's order-dependent fp32 cumsum). */
+int cv_hift_source(const float* f0, const float* phase_vec, const float* noise, const float* lin_w, const float* lin_b,
+                   double* work, float* s, int32_t B, int32_t T, int32_t up, int32_t nh, float sampling_rate,
+                   float sine_amp, float noise_std, float voiced_threshold, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Flow-matching helpers (flow/flow.py:286-317, flow/flow_matching.py:72-124).
+ * ------------------------------------------------------------------------------------------ */
+/* out[r][0:dim] = table[idx[r]][0:dim] (rows with idx < 0 -> zeros); out dtype `dtype`, ld ldo */
+int cv_embedding(const float* table, const int32_t* idx, void* out, int32_t dtype, int32_t rows, int32_t dim, int32_t ldo, void* stream);
+/* Estimator input for classifier-free guidance, channels-last: for utterance b, row pair (2b, 2b+1):
+ *   xin[2b]   = [x | mu | spks (broadcast over T) | cond]   xin[2b+1] = [x | 0 | 0 | 0]      (flow_matching.py:95-108,
+ *   flow/decoder.py:243-249).  x, mu, cond [B][T][C] fp32, spks [B][C] fp32 -> xin [2B][T][4C] `dtype`. */
+int cv_est_pack(const float* x, const float* mu, const float* spks, const float* cond, void* xin, int32_t dtype,
+                int32_t B, int32_t T, int32_t C, void* stream);
+/* Euler step with CFG: x += dt * ((1+w) * v[2b] - w * v[2b+1]);  v [2B][T][C] fp32 (flow_matching.py:116-118) */
+int cv_cfm_update(float* x, const float* v, int32_t B, int32_t T, int32_t C, float dt, float cfg_rate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * hipGraph capture of a launch sequence issued through this ABI on `stream` (the reference's counterpart is
+ * torch.cuda.CUDAGraph capture in llm/qwen2_5.py:97-124).  begin/end bracket the launches; launch replays them.
+ * ------------------------------------------------------------------------------------------ */
+int cv_graph_begin(void* stream);
+int cv_graph_end(void* stream, void** graph_exec_out);
+int cv_graph_launch(void* graph_exec, void* stream);
+int cv_graph_destroy(void* graph_exec);
+
 #ifdef __cplusplus
 }
 #endif
