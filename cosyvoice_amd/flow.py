@@ -1,0 +1,546 @@
+"""Flow-matching mel decoder on MI355X — host side of the drop-in for the reference's
+``CausalMaskedDiffWithXvec`` (/root/reference/cosyvoice/flow/flow.py:163-319), its
+``UpsampleConformerEncoder`` (transformer/upsample_encoder.py:100-318), ``CausalConditionalCFM``
+(flow/flow_matching.py:209-240) and the estimator ``ConditionalDecoder`` (flow/decoder.py:88-334).
+
+Same attribute surface the orchestrator touches: ``.fp16``, ``.input_frame_rate``,
+``.token_mel_ratio``, ``.pre_lookahead_len``, ``.encoder.static_chunk_size``,
+``.decoder.estimator(.static_chunk_size)``, ``inference(...) -> (mel (1,80,T_g) fp32, None)``; same state-dict
+key names.  All arithmetic runs in libcosyvoice_amd.so: channels-last activations, fp32 residual streams,
+16-bit (bf16 / fp16) MFMA operands with fp32 accumulation, flash attention, fused epilogues.
+
+Beyond the reference (which is batch-1 only, flow.py:277): ``inference_batch`` runs B equal-shape utterances in
+one pass (the CFG pair of every utterance is batched: 2B sequences per estimator call).
+"""
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .config import FlowConfig
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class _P:
+    """Device-resident packed parameters, fetched from a state dict by reference key."""
+
+    def __init__(self, sd, dtype, device):
+        self.sd, self.dt, self.dev = sd, dtype, device
+
+    def f32(self, key):
+        return self.sd[key].detach().to(device=self.dev, dtype=torch.float32).contiguous()
+
+    def w(self, key):
+        return self.sd[key].detach().to(torch.float32).to(device=self.dev, dtype=self.dt).contiguous()
+
+    def conv(self, key):
+        """Conv1d weight (Cout,Cin,k) -> (Cout, k*Cin), k = tap*Cin + ci."""
+        w = self.sd[key].detach().to(torch.float32)
+        return w.permute(0, 2, 1).reshape(w.shape[0], -1).to(device=self.dev, dtype=self.dt).contiguous()
+
+
+# =============================================================================== encoder
+class UpsampleConformerEncoder:
+    def __init__(self, cfg: FlowConfig, dtype, device):
+        self.cfg, self.dtype, self.device = cfg, dtype, device
+        self.static_chunk_size = 0
+        self._ws: Dict[tuple, dict] = {}
+        self._pos: Dict[tuple, torch.Tensor] = {}
+
+    def output_size(self):
+        return self.cfg.enc_dim
+
+    def load(self, sd, prefix="encoder."):
+        cfg = self.cfg
+        P = _P(sd, self.dtype, self.device)
+        D = cfg.enc_dim
+
+        def layer(name):
+            a = f"{name}.self_attn."
+            bq = sd[a + "linear_q.bias"].float()
+            wq = sd[a + "linear_q.weight"].float()
+            wqkv = torch.cat([wq, wq, sd[a + "linear_k.weight"].float(), sd[a + "linear_v.weight"].float()], 0)
+            bqkv = torch.cat([bq + sd[a + "pos_bias_u"].float().reshape(-1), bq + sd[a + "pos_bias_v"].float().reshape(-1),
+                              sd[a + "linear_k.bias"].float(), sd[a + "linear_v.bias"].float()], 0)
+            return dict(wqkv=wqkv.to(device=self.device, dtype=self.dtype).contiguous(),
+                        bqkv=bqkv.to(device=self.device).contiguous(),
+                        wpos=P.w(a + "linear_pos.weight"), wout=P.w(a + "linear_out.weight"), bout=P.f32(a + "linear_out.bias"),
+                        w1=P.w(f"{name}.feed_forward.w_1.weight"), b1=P.f32(f"{name}.feed_forward.w_1.bias"),
+                        w2=P.w(f"{name}.feed_forward.w_2.weight"), b2=P.f32(f"{name}.feed_forward.w_2.bias"),
+                        g_mha=P.f32(f"{name}.norm_mha.weight"), b_mha=P.f32(f"{name}.norm_mha.bias"),
+                        g_ff=P.f32(f"{name}.norm_ff.weight"), b_ff=P.f32(f"{name}.norm_ff.bias"))
+
+        def emb(name):
+            return dict(w=P.w(f"{name}.out.0.weight"), b=P.f32(f"{name}.out.0.bias"), g=P.f32(f"{name}.out.1.weight"),
+                        beta=P.f32(f"{name}.out.1.bias"))
+
+        self.embed = emb(prefix + "embed")
+        self.up_embed = emb(prefix + "up_embed")
+        self.pl1_w, self.pl1_b = P.conv(prefix + "pre_lookahead_layer.conv1.weight"), P.f32(prefix + "pre_lookahead_layer.conv1.bias")
+        self.pl2_w, self.pl2_b = P.conv(prefix + "pre_lookahead_layer.conv2.weight"), P.f32(prefix + "pre_lookahead_layer.conv2.bias")
+        self.layers = [layer(f"{prefix}encoders.{i}") for i in range(cfg.enc_blocks)]
+        self.up_layers = [layer(f"{prefix}up_encoders.{i}") for i in range(cfg.enc_up_blocks)]
+        # Upsample1D (nearest x2, left pad 4, conv k5; upsample_encoder.py:59-63) as two 3-tap phase convs:
+        #   out[2q]   = (w0+w1) x[q-2] + (w2+w3) x[q-1] + w4 x[q];  out[2q+1] = w0 x[q-2] + (w1+w2) x[q-1] + (w3+w4) x[q]
+        w = sd[prefix + "up_layer.conv.weight"].float()  # (D, D, 5)
+        ph0 = torch.stack([w[:, :, 0] + w[:, :, 1], w[:, :, 2] + w[:, :, 3], w[:, :, 4]], dim=1)
+        ph1 = torch.stack([w[:, :, 0], w[:, :, 1] + w[:, :, 2], w[:, :, 3] + w[:, :, 4]], dim=1)
+        self.up_w = [p.reshape(D, 3 * D).to(device=self.device, dtype=self.dtype).contiguous() for p in (ph0, ph1)]
+        self.up_b = P.f32(prefix + "up_layer.conv.bias")
+        self.after_g, self.after_b = P.f32(prefix + "after_norm.weight"), P.f32(prefix + "after_norm.bias")
+
+    # ---- rel-pos table (EspnetRelPositionalEncoding, embedding.py:220-294) projected by each layer's linear_pos
+    def _pos_proj(self, layers, tag, T):
+        key = (tag, T)
+        if key in self._pos:
+            return self._pos[key]
+        D = self.cfg.enc_dim
+        pos = torch.arange(T - 1, -T, -1, dtype=torch.float32).unsqueeze(1)
+        div = torch.exp(torch.arange(0, D, 2, dtype=torch.float32) * -(math.log(10000.0) / D))
+        pe = torch.zeros(2 * T - 1, D)
+        pe[:, 0::2] = torch.sin(pos * div)
+        pe[:, 1::2] = torch.cos(pos * div)
+        pe = pe.to(device=self.device, dtype=self.dtype).contiguous()
+        outs = []
+        for l in layers:
+            p = torch.empty(2 * T - 1, D, device=self.device, dtype=self.dtype)
+            ops.linear(pe, l["wpos"], out_act=p)
+            outs.append(p)
+        self._pos[key] = outs
+        return outs
+
+    def _workspace(self, R, N):
+        key = (R, N)
+        if key in self._ws:
+            return self._ws[key]
+        cfg, dt, dev = self.cfg, self.dtype, self.device
+        D, H, U = cfg.enc_dim, cfg.enc_heads, cfg.enc_linear_units
+        e = lambda *s, dtype=torch.float32: torch.empty(*s, device=dev, dtype=dtype)
+        ws = {}
+        for tag, T in (("a", N), ("b", 2 * N)):
+            Tp = _round_up(T, 8)
+            ldb = _round_up(2 * T - 1, 4)
+            ws[tag] = dict(T=T, Tp=Tp, ldb=ldb, xs=e(R, T, D), xn=e(R, T, D, dtype=dt), lin=e(R, T, D),
+                           q=e(R, T, 2 * D, dtype=dt), k=e(R, T, D, dtype=dt), vt=torch.zeros(R, H, 64, Tp, device=dev, dtype=dt),
+                           bd=e(R, H, T, ldb), ao=e(R, T, D, dtype=dt), ff=e(R, T, U, dtype=dt), xa=e(R, T, D, dtype=dt))
+        ws["tok"] = e(R, N, D, dtype=dt)
+        ws["t1"] = e(R, N, D, dtype=dt)
+        ws["up"] = e(R, 2 * N, D, dtype=dt)
+        ws["mu"] = e(R, 2 * N, cfg.output_size)
+        self._ws[key] = ws
+        return ws
+
+    def _layer(self, l, w, R, p_l, chunk, klen, last_act=None):
+        cfg = self.cfg
+        D, H, U = cfg.enc_dim, cfg.enc_heads, cfg.enc_linear_units
+        T, Tp, ldb = w["T"], w["Tp"], w["ldb"]
+        xs = w["xs"]
+        xs2 = xs.view(R * T, D)
+        ops.layernorm(xs2, l["g_mha"], l["b_mha"], 1e-12, out_act=w["xn"].view(R * T, D))
+        ops.gemm(w["xn"], l["wqkv"], T, 4 * D, D, batch=R, a_bs=(T * D, 0), lda=D, bias=l["bqkv"], out_act=w["q"],
+                 oa_bs=(T * 2 * D, 0), ldoa=2 * D,
+                 qkv=dict(q_cols=2 * D, k_cols=D, k_out=w["k"], k_bs=T * D, ldk=D, vt_out=w["vt"], vt_heads=H, vt_ld=Tp))
+        # matrix_bd = (q + pos_bias_v) . p^T per head, pre-scaled by 1/sqrt(dk) (attention.py:317-327)
+        scale = 1.0 / math.sqrt(D // H)
+        ops.gemm(w["q"][:, :, D:], p_l, T, 2 * T - 1, 64, batch=R * H, batch_inner=H, a_bs=(64, T * 2 * D), lda=2 * D,
+                 w_bs=(64, 0), ldw=D, out_scale=scale, out_f32=w["bd"], o32_bs=(T * ldb, H * T * ldb), ldo32=ldb)
+        ops.attention(w["q"], w["k"], w["vt"], w["ao"], B=R, H=H, Hkv=H, Tq=T, Tk=T, scale=scale, q_bs=T * 2 * D, ldq=2 * D,
+                      k_bs=T * D, ldk=D, vt_ld=Tp, o_bs=T * D, ldo=D, klen=klen, chunk=chunk,
+                      bias=w["bd"].view(-1)[T - 1:], bias_bs=H * T * ldb, bias_hs=T * ldb, bias_ld=ldb - 1)
+        ops.linear(w["ao"].view(R * T, D), l["wout"], bias=l["bout"], res=xs2, out_f32=xs2)
+        ops.layernorm(xs2, l["g_ff"], l["b_ff"], 1e-12, out_act=w["xn"].view(R * T, D))
+        ops.linear(w["xn"].view(R * T, D), l["w1"], bias=l["b1"], act=ops.ACT_SILU, out_act=w["ff"].view(R * T, U))
+        ops.linear(w["ff"].view(R * T, U), l["w2"], bias=l["b2"], res=xs2, out_f32=xs2,
+                   out_act=(last_act.view(R * T, D) if last_act is not None else None))
+
+    def _embed(self, e, x_act2d, w, R):
+        T, D = w["T"], self.cfg.enc_dim
+        ops.linear(x_act2d, e["w"], bias=e["b"], out_f32=w["lin"].view(R * T, D))
+        ops.layernorm(w["lin"].view(R * T, D), e["g"], e["beta"], 1e-5, out_scale=math.sqrt(D), out_f32=w["xs"].view(R * T, D),
+                      out_act=w["xa"].view(R * T, D))
+
+    def forward_tokens(self, tok_emb_act, R, N, klen=None):
+        """tok_emb_act: (R,N,512) token embeddings in the operand dtype (already in ws['tok']).
+        Returns ws (ws['b']['xa'] holds after_norm output, 16-bit, (R,2N,512)).  upsample_encoder.py:237-304."""
+        cfg = self.cfg
+        D = cfg.enc_dim
+        ws = self._workspace(R, N)
+        wa, wb = ws["a"], ws["b"]
+        self._embed(self.embed, tok_emb_act.view(R * N, D), wa, R)
+        # PreLookaheadLayer (upsample_encoder.py:81-96): conv k4 looking right (zero beyond the end), leaky 0.01,
+        # conv k3 looking left, residual
+        ops.conv1d_cl(wa["xa"], self.pl1_w, cfg.pre_lookahead_len + 1, pad_left=0, bias=self.pl1_b, act=ops.ACT_LEAKY,
+                      act_slope=0.01, out_act=ws["t1"])
+        ops.conv1d_cl(ws["t1"], self.pl2_w, 3, pad_left=2, bias=self.pl2_b, res=wa["xs"], out_f32=wa["xs"])
+        pa = self._pos_proj(self.layers, "a", N)
+        for i, l in enumerate(self.layers):
+            self._layer(l, wa, R, pa[i], self.static_chunk_size, klen, last_act=(wa["xa"] if i == len(self.layers) - 1 else None))
+        # Upsample1D as two phase convs writing interleaved rows
+        for r in range(2):
+            ops.gemm(wa["xa"], self.up_w[r], N, D, 3 * D, batch=R, a_bs=(N * D, 0), lda=D, a_rows=N, cin=D, tap_base=-2,
+                     tap_step=1, bias=self.up_b, out_act=ws["up"], oa_bs=(2 * N * D, 0), ldoa=D, out_row_stride=2,
+                     out_row_off=r, out_rows=2 * N)
+        self._embed(self.up_embed, ws["up"].view(R * 2 * N, D), wb, R)
+        pb = self._pos_proj(self.up_layers, "b", 2 * N)
+        klen2 = (klen * 2) if klen is not None else None
+        for i, l in enumerate(self.up_layers):
+            self._layer(l, wb, R, pb[i], self.static_chunk_size * 2, klen2)
+        T2 = 2 * N
+        ops.layernorm(wb["xs"].view(R * T2, D), self.after_g, self.after_b, 1e-5, out_act=wb["xa"].view(R * T2, D))
+        return ws
+
+
+# =============================================================================== estimator
+class ConditionalDecoder:
+    """The CFM estimator (flow/decoder.py:88-334, channels=[256], causal).  ``__call__`` keeps the reference slot
+    contract (x,mask,mu,t,spks,cond -> (2,80,T), SURVEY.md §8b level 2); the solver drives ``forward_cl``."""
+
+    def __init__(self, cfg: FlowConfig, dtype, device):
+        self.cfg, self.dtype, self.device = cfg, dtype, device
+        self.static_chunk_size = 0
+        self._ws: Dict[tuple, dict] = {}
+        self._tcache: Dict[tuple, torch.Tensor] = {}
+
+    def load(self, sd, prefix="decoder.estimator."):
+        cfg = self.cfg
+        P = _P(sd, self.dtype, self.device)
+        self.P = P
+
+        def resnet(name):
+            return dict(w1=P.conv(f"{name}.block1.block.0.weight"), b1=P.f32(f"{name}.block1.block.0.bias"),
+                        g1=P.f32(f"{name}.block1.block.2.weight"), be1=P.f32(f"{name}.block1.block.2.bias"),
+                        w2=P.conv(f"{name}.block2.block.0.weight"), b2=P.f32(f"{name}.block2.block.0.bias"),
+                        g2=P.f32(f"{name}.block2.block.2.weight"), be2=P.f32(f"{name}.block2.block.2.bias"),
+                        wr=P.conv(f"{name}.res_conv.weight"), br=P.f32(f"{name}.res_conv.bias"))
+
+        def tblock(name):
+            wqkv = torch.cat([sd[f"{name}.attn1.to_q.weight"].float(), sd[f"{name}.attn1.to_k.weight"].float(),
+                              sd[f"{name}.attn1.to_v.weight"].float()], 0)
+            return dict(g1=P.f32(f"{name}.norm1.weight"), b1=P.f32(f"{name}.norm1.bias"),
+                        wqkv=wqkv.to(device=self.device, dtype=self.dtype).contiguous(),
+                        wo=P.w(f"{name}.attn1.to_out.0.weight"), bo=P.f32(f"{name}.attn1.to_out.0.bias"),
+                        g3=P.f32(f"{name}.norm3.weight"), b3=P.f32(f"{name}.norm3.bias"),
+                        wf1=P.w(f"{name}.ff.net.0.proj.weight"), bf1=P.f32(f"{name}.ff.net.0.proj.bias"),
+                        wf2=P.w(f"{name}.ff.net.2.weight"), bf2=P.f32(f"{name}.ff.net.2.bias"))
+
+        names = [f"{prefix}down_blocks.0"] + [f"{prefix}mid_blocks.{i}" for i in range(cfg.est_mid_blocks)] + [f"{prefix}up_blocks.0"]
+        self.blocks = [dict(res=resnet(f"{n}.0"), tb=[tblock(f"{n}.1.{j}") for j in range(cfg.est_n_blocks)]) for n in names]
+        self.down_w, self.down_b = P.conv(f"{prefix}down_blocks.0.2.weight"), P.f32(f"{prefix}down_blocks.0.2.bias")
+        self.up_w, self.up_b = P.conv(f"{prefix}up_blocks.0.2.weight"), P.f32(f"{prefix}up_blocks.0.2.bias")
+        self.fin_w, self.fin_b = P.conv(f"{prefix}final_block.block.0.weight"), P.f32(f"{prefix}final_block.block.0.bias")
+        self.fin_g, self.fin_be = P.f32(f"{prefix}final_block.block.2.weight"), P.f32(f"{prefix}final_block.block.2.bias")
+        self.proj_w, self.proj_b = P.conv(f"{prefix}final_proj.weight"), P.f32(f"{prefix}final_proj.bias")
+        # time-embedding path (input independent): TimestepEmbedding + every resnet's Mish->Linear, stacked
+        self.t1_w, self.t1_b = P.w(f"{prefix}time_mlp.linear_1.weight"), P.f32(f"{prefix}time_mlp.linear_1.bias")
+        self.t2_w, self.t2_b = P.w(f"{prefix}time_mlp.linear_2.weight"), P.f32(f"{prefix}time_mlp.linear_2.bias")
+        self.tm_w = torch.cat([sd[f"{n}.0.mlp.1.weight"].float() for n in names], 0).to(device=self.device, dtype=self.dtype).contiguous()
+        self.tm_b = torch.cat([sd[f"{n}.0.mlp.1.bias"].float() for n in names], 0).to(device=self.device).contiguous()
+
+    def time_table(self, t_values: List[float]) -> torch.Tensor:
+        """(len(t), n_blocks*C) fp32: the per-resnet additive time term mlp(mish(time_mlp(sinus(t)))) for each step
+        (flow/decoder.py:240-241, components/decoder.py:12-27,56).  Depends only on the step schedule."""
+        key = tuple(round(float(t), 9) for t in t_values)
+        if key in self._tcache:
+            return self._tcache[key]
+        cfg = self.cfg
+        dim = cfg.est_in_channels
+        half = dim // 2
+        t = torch.tensor(t_values, dtype=torch.float32)
+        e = math.log(10000) / (half - 1)
+        e = torch.exp(torch.arange(half, dtype=torch.float32) * -e)
+        e = 1000.0 * t.unsqueeze(1) * e.unsqueeze(0)
+        se = torch.cat((e.sin(), e.cos()), dim=-1)
+        n = len(t_values)
+        npad = _round_up(n, 4)
+        sin_in = torch.zeros(npad, dim)
+        sin_in[:n] = se
+        sin_in = sin_in.to(device=self.device, dtype=self.dtype)
+        td = cfg.est_time_dim
+        h1 = torch.empty(npad, td, device=self.device, dtype=self.dtype)
+        h2 = torch.empty(npad, td, device=self.device, dtype=self.dtype)
+        out = torch.empty(npad, self.tm_w.shape[0], device=self.device)
+        ops.linear(sin_in, self.t1_w, bias=self.t1_b, act=ops.ACT_SILU, out_act=h1)
+        ops.linear(h1, self.t2_w, bias=self.t2_b, act=ops.ACT_MISH, out_act=h2)
+        ops.linear(h2, self.tm_w, bias=self.tm_b, out_f32=out)
+        self._tcache[key] = out
+        return out
+
+    def _workspace(self, R, T):
+        key = (R, T)
+        if key in self._ws:
+            return self._ws[key]
+        cfg, dt, dev = self.cfg, self.dtype, self.device
+        C, inner, ff = cfg.est_channels, cfg.est_inner, cfg.est_channels * cfg.est_ff_mult
+        e = lambda *s, dtype=torch.float32: torch.empty(*s, device=dev, dtype=dtype)
+        Tp = _round_up(T, 8)
+        ws = dict(T=T, Tp=Tp, xin=e(R, T, cfg.est_in_channels, dtype=dt), c32a=e(R, T, C), c32b=e(R, T, C), h1=e(R, T, C, dtype=dt),
+                  x32=e(R, T, C), xn=e(R, T, C, dtype=dt), q=e(R, T, inner, dtype=dt), k=e(R, T, inner, dtype=dt),
+                  vt=torch.zeros(R, cfg.est_heads, 64, Tp, device=dev, dtype=dt), ao=e(R, T, inner, dtype=dt),
+                  ff=e(R, T, ff, dtype=dt), cat=e(R, T, 2 * C, dtype=dt), d=e(R, T, C, dtype=dt), v=e(R, T, cfg.output_size))
+        self._ws[key] = ws
+        return ws
+
+    def _resnet(self, rs, ws, R, a_in, lda, cin, tadd):
+        C, T = self.cfg.est_channels, ws["T"]
+        rows = R * T
+        kw = dict(batch=R, a_bs=(T * lda, 0), lda=lda, a_rows=T)
+        c32a, c32b = ws["c32a"], ws["c32b"]
+        ops.gemm(a_in, rs["w1"], T, C, 3 * cin, cin=cin, tap_base=-2, tap_step=1, bias=rs["b1"], out_f32=c32a,
+                 o32_bs=(T * C, 0), ldo32=C, **kw)
+        ops.layernorm(c32a.view(rows, C), rs["g1"], rs["be1"], 1e-5, act=ops.ACT_MISH, add=tadd, rows_per_group=rows,
+                      out_act=ws["h1"].view(rows, C))
+        ops.gemm(ws["h1"], rs["w2"], T, C, 3 * C, batch=R, a_bs=(T * C, 0), lda=C, a_rows=T, cin=C, tap_base=-2, tap_step=1,
+                 bias=rs["b2"], out_f32=c32a, o32_bs=(T * C, 0), ldo32=C)
+        ops.layernorm(c32a.view(rows, C), rs["g2"], rs["be2"], 1e-5, act=ops.ACT_MISH, out_f32=c32b.view(rows, C))
+        ops.gemm(a_in, rs["wr"], T, C, cin, bias=rs["br"], res=c32b, res_bs=(T * C, 0), ldres=C, out_f32=ws["x32"],
+                 o32_bs=(T * C, 0), ldo32=C, **kw)
+
+    def _tblock(self, tb, ws, R, klen, out_act=None, ldoa=0):
+        cfg = self.cfg
+        C, inner, ff, H = cfg.est_channels, cfg.est_inner, cfg.est_channels * cfg.est_ff_mult, cfg.est_heads
+        T, Tp = ws["T"], ws["Tp"]
+        rows = R * T
+        x2 = ws["x32"].view(rows, C)
+        ops.layernorm(x2, tb["g1"], tb["b1"], 1e-5, out_act=ws["xn"].view(rows, C))
+        ops.gemm(ws["xn"], tb["wqkv"], T, 3 * inner, C, batch=R, a_bs=(T * C, 0), lda=C, out_act=ws["q"], oa_bs=(T * inner, 0),
+                 ldoa=inner, qkv=dict(q_cols=inner, k_cols=inner, k_out=ws["k"], k_bs=T * inner, ldk=inner, vt_out=ws["vt"],
+                                      vt_heads=H, vt_ld=Tp))
+        ops.attention(ws["q"], ws["k"], ws["vt"], ws["ao"], B=R, H=H, Hkv=H, Tq=T, Tk=T, scale=cfg.est_head_dim ** -0.5,
+                      q_bs=T * inner, ldq=inner, k_bs=T * inner, ldk=inner, vt_ld=Tp, o_bs=T * inner, ldo=inner, klen=klen)
+        ops.linear(ws["ao"].view(rows, inner), tb["wo"], bias=tb["bo"], res=x2, out_f32=x2)
+        ops.layernorm(x2, tb["g3"], tb["b3"], 1e-5, out_act=ws["xn"].view(rows, C))
+        ops.linear(ws["xn"].view(rows, C), tb["wf1"], bias=tb["bf1"], act=ops.ACT_GELU, out_act=ws["ff"].view(rows, ff))
+        if out_act is None:
+            ops.linear(ws["ff"].view(rows, ff), tb["wf2"], bias=tb["bf2"], res=x2, out_f32=x2)
+        else:
+            ops.gemm(ws["ff"], tb["wf2"], rows, C, ff, lda=ff, bias=tb["bf2"], res=x2, ldres=C, out_f32=x2, ldo32=C,
+                     out_act=out_act, ldoa=ldoa)
+
+    def forward_cl(self, ws, R, tadd_row: torch.Tensor, klen=None):
+        """ws['xin'] (R,T,320) -> ws['v'] (R,T,80) fp32.  tadd_row: (n_blocks*C,) time terms of this step."""
+        cfg = self.cfg
+        C, T = cfg.est_channels, ws["T"]
+        nb = len(self.blocks)
+        cat = ws["cat"]
+        a_in, lda, cin = ws["xin"], cfg.est_in_channels, cfg.est_in_channels
+        for bi, blk in enumerate(self.blocks):
+            self._resnet(blk["res"], ws, R, a_in, lda, cin, tadd_row[bi * C:(bi + 1) * C])
+            ntb = len(blk["tb"])
+            for j, tb in enumerate(blk["tb"]):
+                last = j == ntb - 1
+                if not last:
+                    self._tblock(tb, ws, R, klen)
+                elif bi == 0:
+                    # skip connection: 16-bit copy into cat[:, :, C:2C] (hiddens.append, decoder.py:277)
+                    self._tblock(tb, ws, R, klen, out_act=cat[:, :, C:], ldoa=2 * C)
+                elif bi == nb - 2:
+                    self._tblock(tb, ws, R, klen, out_act=cat, ldoa=2 * C)  # last mid block -> cat[:, :, 0:C]
+                else:
+                    self._tblock(tb, ws, R, klen, out_act=ws["d"], ldoa=C)
+            if bi == 0:
+                # downsample slot = CausalConv1d k3 on the skip tensor (decoder.py:278)
+                ops.gemm(cat[:, :, C:], self.down_w, T, C, 3 * C, batch=R, a_bs=(T * 2 * C, 0), lda=2 * C, a_rows=T, cin=C,
+                         tap_base=-2, tap_step=1, bias=self.down_b, out_act=ws["d"], oa_bs=(T * C, 0), ldoa=C)
+                a_in, lda, cin = ws["d"], C, C
+            elif bi == nb - 2:
+                a_in, lda, cin = cat, 2 * C, 2 * C
+            else:
+                a_in, lda, cin = ws["d"], C, C
+        # upsample slot = CausalConv1d k3; final block; final_proj (decoder.py:331-334)
+        ops.conv1d_cl(ws["d"], self.up_w, 3, pad_left=2, bias=self.up_b, out_act=ws["h1"])
+        ops.conv1d_cl(ws["h1"], self.fin_w, 3, pad_left=2, bias=self.fin_b, out_f32=ws["c32a"])
+        rows = R * T
+        ops.layernorm(ws["c32a"].view(rows, C), self.fin_g, self.fin_be, 1e-5, act=ops.ACT_MISH, out_act=ws["h1"].view(rows, C))
+        ops.linear(ws["h1"].view(rows, C), self.proj_w, bias=self.proj_b, out_f32=ws["v"].view(rows, cfg.output_size))
+        return ws["v"]
+
+    @torch.no_grad()
+    def __call__(self, x, mask, mu, t, spks, cond, streaming=False):
+        """Reference slot contract: x,mu,cond (R,80,T), mask (R,1,T) (all ones), t (R,), spks (R,80) -> (R,80,T) fp32."""
+        R, Cm, T = x.shape
+        dev = self.device
+        ws = self._workspace(R, T)
+        f = lambda a: a.to(dev, torch.float32).contiguous()
+        xin = torch.cat([f(x), f(mu), f(spks).unsqueeze(-1).expand(-1, -1, T), f(cond)], dim=1).contiguous()  # (R,320,T)
+        ops.to_channels_last(xin, ws["xin"])
+        tt = self.time_table([float(t[0])])
+        self.forward_cl(ws, R, tt[0])
+        out = torch.empty(R, Cm, T, device=dev)
+        ops.to_channels_first(ws["v"], out)
+        return out
+
+
+# =============================================================================== CFM + flow
+class CausalConditionalCFM:
+    def __init__(self, cfg: FlowConfig, estimator: ConditionalDecoder, device):
+        self.cfg, self.estimator, self.device = cfg, estimator, device
+        self.inference_cfg_rate = cfg.inference_cfg_rate
+        # flow_matching.py:212-213: set_all_random_seed(0); rand_noise = randn([1, 80, 50*300]) — regenerated, never stored
+        g_state = torch.get_rng_state()
+        torch.manual_seed(0)
+        self.rand_noise = torch.randn([1, 80, cfg.noise_len])
+        torch.set_rng_state(g_state)
+        self._noise_cl = self.rand_noise[0].t().contiguous().to(device)  # (15000, 80) channels-last
+        self._graphs: Dict[tuple, tuple] = {}
+        self.use_graph = False
+
+    def schedule(self, n_timesteps):
+        """t values fed to the estimator and the dt of every Euler step, with the reference's fp32 accumulation order
+        (flow_matching.py:88,118-122,237-239)."""
+        t_span = torch.linspace(0, 1, n_timesteps + 1, dtype=torch.float32)
+        t_span = 1 - torch.cos(t_span * 0.5 * torch.pi)
+        t, dt = t_span[0], t_span[1] - t_span[0]
+        ts, dts = [], []
+        for step in range(1, n_timesteps + 1):
+            ts.append(float(t))
+            dts.append(float(dt))
+            t = t + dt
+            if step < n_timesteps:
+                dt = t_span[step + 1] - t
+        return ts, dts
+
+    def solve(self, x, mu, spks, cond, n_timesteps, klen=None):
+        """x (B,T,80) fp32 state (updated in place); mu, cond (B,T,80); spks (B,80).  flow_matching.py:72-124."""
+        est = self.estimator
+        B, T, _ = x.shape
+        R = 2 * B
+        ws = est._workspace(R, T)
+        ts, dts = self.schedule(n_timesteps)
+        tt = est.time_table(ts)
+        klen2 = klen.repeat_interleave(2) if klen is not None else None
+
+        def run():
+            for i in range(n_timesteps):
+                ops.est_pack(x, mu, spks, cond, ws["xin"])
+                est.forward_cl(ws, R, tt[i], klen2)
+                ops.cfm_update(x, ws["v"], dts[i], self.inference_cfg_rate)
+
+        if not self.use_graph:
+            run()
+            return x
+        key = (B, T, n_timesteps, x.data_ptr(), mu.data_ptr(), spks.data_ptr(), cond.data_ptr(),
+               0 if klen2 is None else klen2.data_ptr())
+        g = self._graphs.get(key)
+        if g is None:
+            run()  # warm every lazily-built table outside capture
+            torch.cuda.synchronize()
+            g = ops.Graph().capture(run)
+            self._graphs[key] = g
+            return x  # the eager warm-up already produced the result (x was advanced once)
+        g.launch()
+        return x
+
+    @torch.no_grad()
+    def forward(self, mu, mask, n_timesteps, temperature=1.0, spks=None, cond=None):
+        """Reference signature (flow_matching.py:215-240): mu, cond (1,80,T), spks (1,80) -> ((1,80,T) fp32, None)."""
+        B, Cm, T = mu.shape
+        dev = self.device
+        mu_cl = mu.to(dev, torch.float32).transpose(1, 2).contiguous()
+        cond_cl = cond.to(dev, torch.float32).transpose(1, 2).contiguous()
+        x = (self._noise_cl[:T] * temperature).unsqueeze(0).repeat(B, 1, 1).contiguous()
+        self.solve(x, mu_cl, spks.to(dev, torch.float32).contiguous(), cond_cl, n_timesteps)
+        out = torch.empty(B, Cm, T, device=dev)
+        ops.to_channels_first(x, out)
+        return out, None
+
+    __call__ = forward
+
+
+class CausalMaskedDiffWithXvec:
+    def __init__(self, cfg: Optional[FlowConfig] = None, dtype: torch.dtype = torch.bfloat16, device: str = "cuda"):
+        self.cfg = cfg or FlowConfig.full()
+        self.dtype, self.device = dtype, torch.device(device)
+        self.fp16 = False
+        self.input_frame_rate = self.cfg.input_frame_rate
+        self.token_mel_ratio = self.cfg.token_mel_ratio
+        self.pre_lookahead_len = self.cfg.pre_lookahead_len
+        self.output_size = self.cfg.output_size
+        self.encoder = UpsampleConformerEncoder(self.cfg, dtype, self.device)
+        self.decoder = CausalConditionalCFM(self.cfg, ConditionalDecoder(self.cfg, dtype, self.device), self.device)
+        self._loaded = False
+        self._bufs: Dict[tuple, dict] = {}
+
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    def half(self):
+        return self
+
+    def load_state_dict(self, sd, strict: bool = False):
+        sd = {k: v.detach().to("cpu") for k, v in sd.items()}
+        P = _P(sd, self.dtype, self.device)
+        self.emb_table = P.f32("input_embedding.weight")
+        self.spk_w, self.spk_b = P.w("spk_embed_affine_layer.weight"), P.f32("spk_embed_affine_layer.bias")
+        self.proj_w, self.proj_b = P.w("encoder_proj.weight"), P.f32("encoder_proj.bias")
+        self.encoder.load(sd)
+        self.decoder.estimator.load(sd)
+        self._loaded = True
+        return self
+
+    def _buffers(self, B, N, D):
+        key = (B, N, D)
+        if key not in self._bufs:
+            dev = self.device
+            Dp = _round_up(D, 8)
+            self._bufs[key] = dict(idx=torch.empty(B, N, device=dev, dtype=torch.int32),
+                                   emb_in=torch.zeros(B, D, device=dev), emb_n=torch.zeros(B, Dp, device=dev, dtype=self.dtype),
+                                   spks=torch.empty(B, self.cfg.output_size, device=dev),
+                                   cond=torch.zeros(B, 2 * N, self.cfg.output_size, device=dev),
+                                   x=torch.empty(B, 2 * N, self.cfg.output_size, device=dev),
+                                   mel=torch.empty(B, self.cfg.output_size, 2 * N, device=dev))
+        return self._bufs[key]
+
+    @torch.no_grad()
+    def inference_batch(self, tokens: torch.Tensor, prompt_tokens: torch.Tensor, prompt_feats: torch.Tensor,
+                        embeddings: torch.Tensor, n_timesteps: int = 10):
+        """B equal-shape utterances.  tokens (B,Ng) i32, prompt_tokens (B,Np), prompt_feats (B,Tp,80) with Tp = 2*Np,
+        embeddings (B,D) -> mel (B,80,2*Ng) fp32.  Per utterance identical to ``inference`` (flow.py:258-319)."""
+        assert self._loaded
+        cfg, dev = self.cfg, self.device
+        B, Ng = tokens.shape
+        Np = prompt_tokens.shape[1]
+        N = Np + Ng
+        T = 2 * N
+        D = embeddings.shape[1]
+        bf = self._buffers(B, N, D)
+        # speaker: F.normalize -> Linear (flow.py:286-287); RMSNorm kernel with scale 1/sqrt(D) == x / ||x||
+        bf["emb_in"].copy_(embeddings.to(dev, torch.float32))
+        ops.layernorm(bf["emb_in"], None, None, 1e-24 / D, rms=True, out_scale=1.0 / math.sqrt(D), out_act=bf["emb_n"][:, :D])
+        ops.gemm(bf["emb_n"], self.spk_w, B, cfg.output_size, D, lda=bf["emb_n"].stride(0), bias=self.spk_b, out_f32=bf["spks"],
+                 ldo32=cfg.output_size)
+        # tokens -> embedding -> encoder -> encoder_proj = mu (flow.py:290-302)
+        bf["idx"][:, :Np].copy_(prompt_tokens.to(dev, torch.int32))
+        bf["idx"][:, Np:].copy_(tokens.to(dev, torch.int32))
+        ews = self.encoder._workspace(B, N)
+        ops.embedding(self.emb_table, bf["idx"].view(-1), ews["tok"].view(B * N, cfg.enc_dim))
+        self.encoder.forward_tokens(ews["tok"], B, N)
+        ops.linear(ews["b"]["xa"].view(B * T, cfg.enc_dim), self.proj_w, bias=self.proj_b, out_f32=ews["mu"].view(B * T, cfg.output_size))
+        # conditions: prompt mel then zeros (flow.py:305-307)
+        Tp = prompt_feats.shape[1]
+        bf["cond"].zero_()
+        bf["cond"][:, :Tp].copy_(prompt_feats.to(dev, torch.float32))
+        bf["x"].copy_(self.decoder._noise_cl[:T].unsqueeze(0).expand(B, -1, -1))
+        self.decoder.solve(bf["x"], ews["mu"], bf["spks"], bf["cond"], n_timesteps)
+        ops.to_channels_first(bf["x"], bf["mel"])
+        return bf["mel"][:, :, Tp:]
+
+    @torch.no_grad()
+    def inference(self, token, token_len, prompt_token, prompt_token_len, prompt_feat, prompt_feat_len, embedding,
+                  flow_cache=None, sample_rate=24000, n_timesteps=10, begin=False, finalize=True):
+        """Reference signature (flow.py:260-272) -> (mel (1,80,T_g) float32, None)."""
+        assert token.shape[0] == 1
+        r = self.token_mel_ratio
+        if int(prompt_feat_len[0]) % r != 0:  # flow.py:279-283 (mutates the length tensors in place, as the reference)
+            prompt_feat_len[0] -= prompt_feat_len[0] % r
+            prompt_feat = prompt_feat[:, :int(prompt_feat_len[0]), :]
+            prompt_token_len[0] = prompt_feat_len[0] // r
+            prompt_token = prompt_token[:, :int(prompt_token_len[0])]
+        mel = self.inference_batch(token, prompt_token, prompt_feat, embedding, n_timesteps)
+        return mel.float().clone(), None

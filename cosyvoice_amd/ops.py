@@ -149,3 +149,58 @@ def hift_source(f0, phase_vec, noise, lin_w, lin_b, work, s, up, sampling_rate, 
                                    C.c_void_p(lin_w.data_ptr()), C.c_void_p(lin_b.data_ptr()), C.c_void_p(work.data_ptr()),
                                    C.c_void_p(s.data_ptr()), B, T, up, nh, C.c_float(sampling_rate), C.c_float(sine_amp),
                                    C.c_float(noise_std), C.c_float(vthr), L.stream_ptr()), "cv_hift_source")
+
+
+# ----------------------------------------------------------------------------- flow helpers / graphs
+def embedding(table, idx, out):
+    """table (V,dim) fp32, idx (rows,) int32, out (rows, ld) any dtype."""
+    _req_cuda(table, idx, out)
+    L.check(L.lib().cv_embedding(C.c_void_p(table.data_ptr()), C.c_void_p(idx.data_ptr()), C.c_void_p(out.data_ptr()),
+                                 L.TORCH_DT[out.dtype], idx.numel(), table.shape[1], out.stride(-2), L.stream_ptr()), "cv_embedding")
+
+
+def est_pack(x, mu, spks, cond, xin):
+    _req_cuda(x, mu, spks, cond, xin)
+    B, T, Cc = x.shape
+    L.check(L.lib().cv_est_pack(C.c_void_p(x.data_ptr()), C.c_void_p(mu.data_ptr()), C.c_void_p(spks.data_ptr()),
+                                C.c_void_p(cond.data_ptr()), C.c_void_p(xin.data_ptr()), L.TORCH_DT[xin.dtype], B, T, Cc,
+                                L.stream_ptr()), "cv_est_pack")
+
+
+def cfm_update(x, v, dt, cfg_rate):
+    _req_cuda(x, v)
+    B, T, Cc = x.shape
+    L.check(L.lib().cv_cfm_update(C.c_void_p(x.data_ptr()), C.c_void_p(v.data_ptr()), B, T, Cc, C.c_float(dt), C.c_float(cfg_rate),
+                                  L.stream_ptr()), "cv_cfm_update")
+
+
+class Graph:
+    """hipGraph of a launch sequence issued through the ABI on torch's current stream."""
+
+    def __init__(self):
+        self.handle = C.c_void_p(None)
+
+    def capture(self, fn):
+        # capture needs a non-default stream; replays may go to any stream
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            st = L.stream_ptr()
+            L.check(L.lib().cv_graph_begin(st), "cv_graph_begin")
+            try:
+                fn()
+            finally:
+                rc = L.lib().cv_graph_end(st, C.byref(self.handle))
+            L.check(rc, "cv_graph_end")
+        torch.cuda.current_stream().wait_stream(side)
+        return self
+
+    def launch(self):
+        L.check(L.lib().cv_graph_launch(self.handle, L.stream_ptr()), "cv_graph_launch")
+
+    def __del__(self):
+        try:
+            if self.handle:
+                L.lib().cv_graph_destroy(self.handle)
+        except Exception:
+            pass

@@ -159,6 +159,70 @@ int cv_graph_end(void* stream, void** graph_exec_out);
 int cv_graph_launch(void* graph_exec, void* stream);
 int cv_graph_destroy(void* graph_exec);
 
+/* ------------------------------------------------------------------------------------------
+ * LLM decode-step kernels (Qwen2 backbone; HF Qwen2ForCausalLM called from llm/llm.py:754-766; the reference's own
+ * CUDA-graph decode path llm/qwen2_5.py:97-179,265-320 is the behavioural spec of the captured token loop).
+ * ------------------------------------------------------------------------------------------ */
+/* Skinny GEMM for M <= 16 rows (decode batch): out[m][n] = sum_k A[m][k] * W[n][k], weights pre-packed by
+ * cv_pack_skinny into MFMA 16x16x32 B-fragments [N/16][K/32][64 lanes][8] so every wave-load is 1 KiB contiguous
+ * (HBM-bound weight streaming).  A: [16][lda] 16-bit (rows >= M must be finite, e.g. zero).
+ * mode 0: out_f32[ks][m][n] (+bias on slice 0), ksplit slabs of slab_stride floats;
+ * mode 1: out_f32[m][n] += acc + bias (in-place residual, ksplit must be 1);
+ * mode 2: SwiGLU: tiles alternate [gate16 | up16]; out_act[m][16*pair + i] = silu(g) * u (ksplit must be 1). */
+typedef struct cv_skinny_params {
+  int32_t dtype, M, N, K;
+  const void* A; int32_t lda;
+  const void* Wp;
+  const float* bias;
+  int32_t ksplit, mode;
+  float* out_f32; int32_t ldo; int64_t slab_stride;
+  void* out_act; int32_t ldoa;
+} cv_skinny_params;
+int cv_skinny_gemm(const cv_skinny_params* p, void* stream);
+/* W [N][K] row-major 16-bit (device) -> packed (device), N padded up to a multiple of 16 with zeros.
+ * interleave != 0: rows are taken as [gate(N/2) ; up(N/2)] and emitted as alternating 16-row blocks. */
+int cv_pack_skinny(const void* W, void* Wp, int32_t N, int32_t K, int32_t interleave, void* stream);
+
+/* x[b][:] += sum_s slab[s][b][:] (nslab may be 0); xn[b][:] = T(rmsnorm(x[b]) * gamma).  One workgroup per row. */
+int cv_rmsnorm_reduce(float* x, int32_t ldx, const float* slabs, int32_t nslab, int64_t slab_stride, int32_t ld_slab,
+                      const float* gamma, float eps, void* xn, int32_t ldxn, int32_t dtype, int32_t rows, int32_t dim, void* stream);
+
+/* RoPE (HF rotate_half convention) + KV-cache append.  qkv fp32 [rows][ldqkv] = [q (Hq*64) | k (Hkv*64) | v (Hkv*64)];
+ * row r belongs to sequence b = r / rows_per_seq at position pos_base[b] + r % rows_per_seq.
+ * q_out [rows][ldq] 16-bit; kcache [B][Hkv][ctx_max][64]; vtcache [B][Hkv][64][ctx_max] (16-bit). */
+int cv_rope_append(const float* qkv, int32_t ldqkv, const int32_t* pos_base, int32_t rows, int32_t rows_per_seq,
+                   int32_t Hq, int32_t Hkv, const float* inv_freq, void* q_out, int32_t ldq, void* kcache, void* vtcache,
+                   int32_t ctx_max, int32_t dtype, void* stream);
+
+/* Single-query GQA attention over the KV cache: for sequence b, kv head hk, the Hq/Hkv query heads of the group
+ * form the (<=16) columns of one MFMA tile; 4 waves split the keys and merge by log-sum-exp.
+ * q [B][ldq] 16-bit (row b), ctx_len[b] keys valid; out [B][ldo] 16-bit. */
+int cv_decode_attention(const void* q, int32_t ldq, const void* kcache, const void* vtcache, const int32_t* ctx_len,
+                        int32_t ctx_add, void* out, int32_t ldo, int32_t B, int32_t Hq, int32_t Hkv, int32_t ctx_max,
+                        float scale, int32_t dtype, void* stream);
+
+/* Repetition-aware sampling on device (utils/common.py:109-146 ras_sampling/nucleus_sampling/random_sampling,
+ * llm/llm.py:806-821 sampling_ids, :861-874 loop bookkeeping).  One workgroup per sequence. */
+typedef struct cv_sample_params {
+  const float* logits; int32_t ldl; int32_t V; int32_t B;
+  int32_t eos; int32_t top_k; float top_p; int32_t win_size; float tau_r;
+  uint64_t seed;
+  const float* uniforms;      /* optional [B][max_trials+1][2] injected uniforms (tests); null -> Philox */
+  int32_t max_trials;
+  const int32_t* min_len; const int32_t* max_len;   /* [B] */
+  const int32_t* forced; int32_t forced_ld;         /* [B][forced_ld] teacher-forced emitted ids, -1 = none; or null */
+  int32_t* step;              /* [B] loop index i of llm.py:861 */
+  int32_t* pos;               /* [B] KV length, +1 per step */
+  int32_t* n_emitted;         /* [B] */
+  int32_t* finished;          /* [B] 0 running, 1 eos, 2 max_len, 3 sampling stalled (max_trials) */
+  int32_t* out_tokens; int32_t out_ld;              /* [B][out_ld] */
+  const float* emb_table; int32_t emb_dim;          /* speech_embedding.weight fp32 */
+  float* x; int32_t ldx;      /* next-step input embedding [B][ldx] */
+} cv_sample_params;
+int cv_sample_ras(const cv_sample_params* p, void* stream);
+int cv_sizeof_skinny_params(void);
+int cv_sizeof_sample_params(void);
+
 #ifdef __cplusplus
 }
 #endif

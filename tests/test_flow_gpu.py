@@ -1,0 +1,105 @@
+"""GPU: the HIP flow path (cosyvoice_amd.flow, through the C ABI) against the reference-minted goldens and the
+CPU oracle.  Tolerances: bf16/fp16 MFMA operands with fp32 accumulation vs an fp32 reference; the reference's own
+precedent for an estimator-backend swap is rtol 1e-2 (bin/export_onnx.py:100)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cosyvoice_amd.config import FlowConfig
+from cosyvoice_amd.weights import flow_state_dict
+
+pytestmark = pytest.mark.gpu
+
+DTS = [(torch.bfloat16, 4e-2, 8e-3), (torch.float16, 6e-3, 1.2e-3)]  # (dtype, L-inf tol, mean-abs tol)
+
+
+def _golden(golden_dir, name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, name + ".npz")).items()}
+
+
+def _report(name, got, ref):
+    d = (got.float().cpu() - ref).abs()
+    print(f"{name}: Linf {d.max().item():.3e} L1 {d.mean().item():.3e} ref-absmean {ref.abs().mean().item():.3e}")
+    return d.max().item(), d.mean().item()
+
+
+@pytest.mark.parametrize("dt,linf,l1", DTS)
+def test_estimator_slot_vs_golden(golden_dir, dt, linf, l1):
+    from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
+    for name, cfg in (("flow_tiny", FlowConfig.tiny()),
+                      ("flow_est_1block", FlowConfig(est_n_blocks=1, est_mid_blocks=1, enc_blocks=1, enc_up_blocks=1, vocab_size=64))):
+        g = _golden(golden_dir, name)
+        flow = CausalMaskedDiffWithXvec(cfg, dtype=dt).load_state_dict(flow_state_dict(cfg))
+        T = g["est_x"].shape[-1]
+        out = flow.decoder.estimator(g["est_x"].cuda(), torch.ones(2, 1, T).cuda(), g["est_mu"].cuda(), g["est_t"].cuda(),
+                                     g["est_spks"].cuda(), g["est_cond"].cuda())
+        a, b = _report(f"estimator[{name},{dt}]", out, g["est_out"])
+        assert a < linf and b < l1
+
+
+@pytest.mark.parametrize("dt,linf,l1", DTS)
+@pytest.mark.parametrize("chunk,key", [(0, "enc_full"), (4, "enc_chunk4")])
+def test_encoder_vs_golden(golden_dir, dt, linf, l1, chunk, key):
+    from cosyvoice_amd import ops
+    from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
+    cfg = FlowConfig.tiny()
+    g = _golden(golden_dir, "flow_tiny")
+    flow = CausalMaskedDiffWithXvec(cfg, dtype=dt).load_state_dict(flow_state_dict(cfg))
+    enc = flow.encoder
+    enc.static_chunk_size = chunk
+    x = g["enc_in"].cuda()
+    R, N, D = x.shape
+    ws = enc._workspace(R, N)
+    ws["tok"].copy_(x.to(dt))
+    enc.forward_tokens(ws["tok"], R, N)
+    torch.cuda.synchronize()
+    a, b = _report(f"encoder[{key},{dt}]", ws["b"]["xa"], g[key])
+    assert a < linf * 2 and b < l1 * 2  # LayerNorm output, unit scale, stored in 16-bit
+
+
+@pytest.mark.parametrize("dt,linf,l1", DTS)
+@pytest.mark.parametrize("chunk,key", [(0, "mel_full"), (4, "mel_chunk4")])
+def test_inference_vs_golden(golden_dir, dt, linf, l1, chunk, key):
+    from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
+    cfg = FlowConfig.tiny()
+    g = _golden(golden_dir, "flow_tiny")
+    flow = CausalMaskedDiffWithXvec(cfg, dtype=dt).load_state_dict(flow_state_dict(cfg))
+    flow.encoder.static_chunk_size = chunk
+    n_g, n_p = g["token"].shape[1], g["prompt_token"].shape[1]
+    mel, _ = flow.inference(token=g["token"], token_len=torch.tensor([n_g]), prompt_token=g["prompt_token"],
+                            prompt_token_len=torch.tensor([n_p]), prompt_feat=g["prompt_feat"],
+                            prompt_feat_len=torch.tensor([2 * n_p]), embedding=g["embedding"])
+    assert mel.shape == g[key].shape and mel.dtype == torch.float32
+    a, b = _report(f"mel[{key},{dt}]", mel, g[key])
+    assert a < linf * 2 and b < l1 * 2
+
+
+@pytest.mark.parametrize("dt,linf,l1", DTS)
+def test_inference_vs_oracle_larger_and_batched(dt, linf, l1):
+    """N_p=20, N_g=45 (T=130: two attention query tiles, ragged tile edges) against the oracle; batch of 3 equals
+    three batch-1 runs; hipGraph replay equals the eager launch sequence."""
+    from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
+    from oracle import flow as of
+    cfg = FlowConfig.tiny()
+    sd = flow_state_dict(cfg)
+    flow = CausalMaskedDiffWithXvec(cfg, dtype=dt).load_state_dict(sd)
+    g = torch.Generator().manual_seed(7)
+    B, n_p, n_g = 3, 20, 45
+    tok = torch.randint(0, cfg.vocab_size, (B, n_g), generator=g, dtype=torch.int32)
+    ptok = torch.randint(0, cfg.vocab_size, (B, n_p), generator=g, dtype=torch.int32)
+    pfeat = torch.clamp(torch.randn(B, 2 * n_p, 80, generator=g) * 2 - 6, -11.5, 2.0)
+    emb = torch.randn(B, cfg.spk_embed_dim, generator=g)
+    ref0 = of.inference(sd, cfg, tok[:1], ptok[:1], pfeat[:1], emb[:1])
+    mb = flow.inference_batch(tok, ptok, pfeat, emb).clone()
+    a, b = _report(f"mel[T=130,{dt}]", mb[:1], ref0)
+    assert a < linf * 2 and b < l1 * 2
+    for i in range(B):
+        m1 = flow.inference_batch(tok[i:i + 1], ptok[i:i + 1], pfeat[i:i + 1], emb[i:i + 1])
+        assert (m1[0] - mb[i]).abs().max().item() < 1e-5
+    flow.decoder.use_graph = True
+    flow.inference_batch(tok, ptok, pfeat, emb)          # captures
+    mg = flow.inference_batch(tok, ptok, pfeat, emb).clone()  # replays
+    torch.cuda.synchronize()
+    assert (mg - mb).abs().max().item() < 1e-6
