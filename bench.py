@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py — audio-seconds per wall-second of the LLM -> flow -> HiFT hot path on MI355X.
+
+Workload (BASELINE.json configs[3], "Full LLM->flow->hifigan pipeline, batch 8 x 10 s utterances, 1xMI355X with
+hipGraph token loop"): per GPU 8 utterances, each a 10 s prompt (N_p=250 prompt speech tokens,
+T_p=500 prompt mel frames, 10 prompt-text + 20 text ids -> prefill length 282) generating N_g=250 teacher-forced
+speech tokens = 10.0 s of 24 kHz audio; flow T = 1000 frames, 10 CFG Euler steps; HiFT 500 frames -> 240 000 samples.
+One "step" = the whole batch through the pipeline (prefill + 249 graph-replayed decode steps incl. on-device sampling,
+flow encoder + solver, HiFT, waveform D2H).  Synthetic inputs + key-seeded random weights of the reference's
+architecture (no checkpoint exists offline); inputs are resident in HBM before the timed region.
+
+N>1: one process per GPU (torchrun), utterances sharded 8 per rank (weak scaling), ONE RCCL broadcast per step of the
+shared prompt conditioning from rank 0; barrier + synchronize bracket the timed region, MAX over ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+UTT_PER_GPU = 8
+N_PROMPT, N_GEN, L_TEXT, L_PTEXT = 250, 250, 20, 10
+AUDIO_S_PER_UTT = N_GEN * 2 * 480 / 24000.0  # 10.0 s
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_inputs(lc, fc, seed):
+    g = torch.Generator().manual_seed(seed)
+    B = UTT_PER_GPU
+    texts = [torch.randint(0, lc.vocab_size, (1, L_TEXT), generator=g, dtype=torch.int32) for _ in range(B)]
+    forced = [torch.randint(0, lc.speech_token_size, (N_GEN,), generator=g).tolist() for _ in range(B)]
+    # shared prompt conditioning (one speaker prompt for the whole batch: what the broadcast carries)
+    ptext = torch.randint(0, lc.vocab_size, (1, L_PTEXT), generator=g, dtype=torch.int32)
+    pspeech = torch.randint(0, lc.speech_token_size, (1, N_PROMPT), generator=g, dtype=torch.int32)
+    pfeat = torch.clamp(torch.randn(1, 2 * N_PROMPT, 80, generator=g) * 2 - 6, -11.5, 2.0)
+    emb = torch.randn(1, fc.spk_embed_dim, generator=g)
+    return texts, forced, ptext, pspeech, pfeat, emb
+
+
+def cpu_baseline(lsd, fsd, hsd, lc, fc, hc):
+    """The oracle (CPU port of the reference arithmetic) timed on this host's cores on a bounded sample of the SAME
+    workload, extrapolated linearly in the repeated units (decode steps, Euler steps, mel frames)."""
+    from oracle import flow as of
+    from oracle import hift as oh
+    from oracle import llm as ol
+    cores = torch.get_num_threads()
+    g = torch.Generator().manual_seed(1)
+    with torch.inference_mode():
+        # LLM: prefill L=282 + 6 decode steps
+        x = torch.randn(1, 1 + L_PTEXT + L_TEXT + 1 + N_PROMPT, lc.hidden_size, generator=g) * 0.02
+        cache = ol.KVCache(lc.num_layers)
+        t0 = time.perf_counter(); y = ol.qwen2_forward(lsd, lc, x, cache); ol.logits_to_logp(lsd, y[:, -1]); t_pre = time.perf_counter() - t0
+        x1 = torch.randn(1, 1, lc.hidden_size, generator=g) * 0.02
+        ol.qwen2_forward(lsd, lc, x1, cache)
+        t0 = time.perf_counter()
+        for _ in range(6):
+            y = ol.qwen2_forward(lsd, lc, x1, cache); ol.logits_to_logp(lsd, y[:, -1])
+        t_step = (time.perf_counter() - t0) / 6
+        # flow: encoder N=500 once + ONE estimator call at T=1000 (CFG batch 2)
+        N = N_PROMPT + N_GEN
+        xs = torch.randn(1, N, fc.input_size, generator=g)
+        t0 = time.perf_counter(); of.encoder_forward(fsd, fc, xs, torch.tensor([N]), 0); t_enc = time.perf_counter() - t0
+        T = 2 * N
+        a = lambda *s: torch.randn(*s, generator=g)
+        t0 = time.perf_counter()
+        of.estimator_forward(fsd, fc, a(2, 80, T), torch.ones(2, 1, T), a(2, 80, T), torch.tensor([0.5, 0.5]), a(2, 80), a(2, 80, T))
+        t_est = time.perf_counter() - t0
+        # HiFT: 100 of the 500 frames
+        mel = torch.clamp(a(1, 80, 100) * 2 - 6, -11.5, 2.0)
+        ph, nz = oh.draw_source_randoms(hc, 1, 100 * hc.total_upsample, seed=2)
+        t0 = time.perf_counter(); oh.inference(hsd, hc, mel, None, ph, nz); t_hift = (time.perf_counter() - t0) * 5
+    per_utt = t_pre + (N_GEN - 1) * t_step + t_enc + fc.n_timesteps * t_est + t_hift
+    return {"value": round(AUDIO_S_PER_UTT / per_utt, 4), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
+            "sample": (f"oracle fp32, 1 utterance of the same workload: prefill L=282 ({t_pre:.2f}s) + 6 decode steps "
+                       f"({t_step*1e3:.1f} ms/step, x249) + flow encoder N=500 ({t_enc:.2f}s) + 1 estimator call T=1000 "
+                       f"({t_est:.2f}s, x10) + HiFT 100/500 frames (x5 = {t_hift:.2f}s); per-utterance {per_utt:.1f}s")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flow-dtype", default="fp16", choices=["fp16", "bf16"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from cosyvoice_amd.config import FlowConfig, HiftConfig, LlmConfig
+    from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
+    from cosyvoice_amd.hift import HiFTGenerator
+    from cosyvoice_amd.llm import Qwen2LM
+    from cosyvoice_amd.model import CosyVoice2Model
+    from cosyvoice_amd.weights import flow_state_dict, hift_state_dict, llm_state_dict
+
+    lc, fc, hc = LlmConfig.full(), FlowConfig.full(), HiftConfig.v2()
+    t0 = time.time()
+    lsd, fsd, hsd = llm_state_dict(lc), flow_state_dict(fc), hift_state_dict(hc)
+    log(f"[rank {rank}] synthetic weights generated in {time.time()-t0:.1f}s")
+    fdt = torch.float16 if args.flow_dtype == "fp16" else torch.bfloat16
+    llm = Qwen2LM(lc, dtype=torch.bfloat16, max_batch=UTT_PER_GPU, ctx_max=576, max_out=N_GEN + 8)
+    flow = CausalMaskedDiffWithXvec(fc, dtype=fdt)
+    hift = HiFTGenerator(hc, dtype=torch.float32)
+    model = CosyVoice2Model(llm, flow, hift, fp16=False).load_state_dicts(lsd, fsd, hsd)
+    # the fork drives CosyVoice2 modules through CosyVoiceModel wiring (full attention, model.py:50); the benchmark keeps
+    # CosyVoice2Model's own chunk-50 encoder mask (model.py:314)
+    flow.decoder.use_graph = True
+    log(f"[rank {rank}] models on device in {time.time()-t0:.1f}s")
+
+    texts, forced, ptext, pspeech, pfeat, emb = make_inputs(lc, fc, seed=100 + rank)
+    dev = torch.device("cuda", local_rank)
+    B = UTT_PER_GPU
+    # conditioning buffer broadcast from rank 0: [prompt mel | speaker embedding | prompt speech tokens | prompt text ids]
+    n_feat, n_emb = pfeat.numel(), emb.numel()
+    cond_buf = torch.cat([pfeat.reshape(-1), emb.reshape(-1), pspeech.reshape(-1).float(), ptext.reshape(-1).float()]).to(dev)
+    texts_d = [t.to(dev) for t in texts]
+
+    def one_step():
+        if dist is not None:
+            dist.broadcast(cond_buf, src=0)
+        pf = cond_buf[:n_feat].view(1, 2 * N_PROMPT, 80)
+        em = cond_buf[n_feat:n_feat + n_emb].view(1, -1)
+        ps = cond_buf[n_feat + n_emb:n_feat + n_emb + N_PROMPT].to(torch.int32).view(1, -1)
+        pt = cond_buf[n_feat + n_emb + N_PROMPT:].to(torch.int32).view(1, -1)
+        wav = model.tts_batch(texts_d, [pt] * B, [ps] * B, ps.expand(B, -1), pf.expand(B, -1, -1), em.expand(B, -1),
+                              forced=forced, to_host=True)
+        return wav
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        w = one_step()
+        log(f"[rank {rank}] warmup {i}: wav {tuple(w.shape)} absmax {w.abs().max().item():.3f}")
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel, measured live with events on the launch stream
+    roof = measure_roofline(llm, lc)
+
+    out = None
+    if rank == 0:
+        audio_s = AUDIO_S_PER_UTT * B * world * args.steps
+        out = {
+            "metric": "audio-seconds/sec (RTF^-1) end-to-end, 10s prompt, batch 8",
+            "value": round(audio_s / elapsed, 3), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": f"llm bf16 / flow {args.flow_dtype} MFMA operands, fp32 accumulate; hift f32 MFMA",
+            "data": "synthetic (key-seeded random weights of the reference architecture, teacher-forced 250 tokens)",
+            "config": {"workload": "C4 full LLM->flow->HiFT pipeline, 8 utterances x 10 s per GPU, 10 s prompt "
+                                   "(prefill 282, N_g 250, flow T 1000 x 10 CFG Euler steps, HiFT 500 frames)",
+                       "utterances_per_gpu": B, "rtf": round(elapsed / audio_s, 6), "parallelism": f"utterance-parallel x{world}"},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(lsd, fsd, hsd, lc, fc, hc)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def measure_roofline(llm, lc):
+    """Dominant kernel = the decode step's gate/up skinny GEMM (skinny_kernel<bf16,2>): streams the layer's
+    2*4864*896 bf16 gate/up weights once per launch for all 8 sequences.  Algorithmic bytes per launch = packed
+    weight bytes + activations in (16x896 bf16) + SwiGLU out (8x4864 bf16) — DESIGN.md "Roofline"."""
+    from cosyvoice_amd import ops
+    st, lay = llm.st, llm.layers
+    H, I = lc.hidden_size, lc.intermediate_size
+    B = UTT_PER_GPU
+    n_iter = 20
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    # cycle through all 24 layers' weights (417 MB > 256 MB Infinity Cache) so every launch streams from HBM
+    for l in lay:
+        ops.skinny_gemm(st["xn"], l["p_gu"], B, 2 * I, H, mode=2, out_act=st["h"], ldoa=I)
+    ev0.record()
+    for _ in range(n_iter):
+        for l in lay:
+            ops.skinny_gemm(st["xn"], l["p_gu"], B, 2 * I, H, mode=2, out_act=st["h"], ldoa=I)
+    ev1.record()
+    torch.cuda.synchronize()
+    dur = ev0.elapsed_time(ev1) * 1e-3 / (n_iter * len(lay))
+    alg = 2 * I * H * 2 + 16 * H * 2 + B * I * 2
+    return {"bound": "hbm", "kernel": "skinny_kernel<bf16,2> (decode gate/up + SwiGLU)", "achieved": round(alg / dur / 1e9, 1),
+            "peak": 8000.0, "unit": "GB/s", "frac": round(alg / dur / 8e12, 4), "traffic": None,
+            "bytes_per_launch": alg, "avg_launch_us": round(dur * 1e6, 3)}
+
+
+if __name__ == "__main__":
+    main()

@@ -60,6 +60,33 @@ class AttnParams(C.Structure):
         ("scale", _f32),
         ("klen", _vp), ("chunk", _i32), ("causal", _i32), ("causal_off", _i32),
         ("bias", _vp), ("bias_bs", _i64), ("bias_hs", _i64), ("bias_ld", _i32),
+        ("q_hs", _i64), ("k_hs", _i64),
+    ]
+
+
+class SkinnyParams(C.Structure):
+    _fields_ = [
+        ("dtype", _i32), ("M", _i32), ("N", _i32), ("K", _i32),
+        ("A", _vp), ("lda", _i32),
+        ("Wp", _vp), ("bias", _vp),
+        ("ksplit", _i32), ("mode", _i32),
+        ("out_f32", _vp), ("ldo", _i32), ("slab_stride", _i64),
+        ("out_act", _vp), ("ldoa", _i32),
+    ]
+
+
+class SampleParams(C.Structure):
+    _fields_ = [
+        ("logits", _vp), ("ldl", _i32), ("V", _i32), ("B", _i32),
+        ("eos", _i32), ("top_k", _i32), ("top_p", _f32), ("win_size", _i32), ("tau_r", _f32),
+        ("seed", C.c_uint64),
+        ("uniforms", _vp), ("max_trials", _i32),
+        ("min_len", _vp), ("max_len", _vp),
+        ("forced", _vp), ("forced_ld", _i32),
+        ("step", _vp), ("pos", _vp), ("n_emitted", _vp), ("finished", _vp),
+        ("out_tokens", _vp), ("out_ld", _i32),
+        ("emb_table", _vp), ("emb_dim", _i32),
+        ("x", _vp), ("ldx", _i32),
     ]
 
 
@@ -76,7 +103,8 @@ def lib():
                 "cosyvoice_amd has no CPU fallback.")
         _lib = C.CDLL(LIB_PATH)
         _lib.cv_arch.restype = C.c_char_p
-        for name, st in (("gemm", GemmParams), ("norm", NormParams), ("attn", AttnParams)):
+        for name, st in (("gemm", GemmParams), ("norm", NormParams), ("attn", AttnParams), ("skinny", SkinnyParams),
+                         ("sample", SampleParams)):
             fn = getattr(_lib, f"cv_sizeof_{name}_params")
             if fn() != C.sizeof(st):
                 raise RuntimeError(f"ABI mismatch for cv_{name}_params: C {fn()} vs ctypes {C.sizeof(st)}")
@@ -87,7 +115,8 @@ EXPORTS = ["cv_version", "cv_arch", "cv_gemm", "cv_layernorm", "cv_attention",
            "cv_sizeof_gemm_params", "cv_sizeof_norm_params", "cv_sizeof_attn_params",
            "cv_to_channels_last", "cv_to_channels_first", "cv_snake_multi", "cv_stft16", "cv_istft16", "cv_hift_source",
            "cv_embedding", "cv_est_pack", "cv_cfm_update", "cv_graph_begin", "cv_graph_end", "cv_graph_launch",
-           "cv_graph_destroy"]
+           "cv_graph_destroy", "cv_skinny_gemm", "cv_pack_skinny", "cv_rmsnorm_reduce", "cv_rope_append",
+           "cv_decode_attention", "cv_sample_ras", "cv_sizeof_skinny_params", "cv_sizeof_sample_params"]
 
 TORCH_DT = {torch.float32: CV_F32, torch.bfloat16: CV_BF16, torch.float16: CV_F16}
 DT_TORCH = {v: k for k, v in TORCH_DT.items()}

@@ -28,8 +28,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const cv_attn_params p) {
   const int q_wg = blockIdx.x * 128;
   const int q0 = q_wg + wid * 32;
 
-  const uint16_t* Q = (const uint16_t*)p.q + (int64_t)b * p.q_bs + h * 64;
-  const uint16_t* Kp = (const uint16_t*)p.k + (int64_t)b * p.k_bs + hk * 64;
+  const uint16_t* Q = (const uint16_t*)p.q + (int64_t)b * p.q_bs + h * p.q_hs;
+  const uint16_t* Kp = (const uint16_t*)p.k + (int64_t)b * p.k_bs + hk * p.k_hs;
   const uint16_t* Vt = (const uint16_t*)p.vt + (int64_t)(b * p.Hkv + hk) * 64 * p.vt_ld;
   const int klen = p.klen ? min(p.klen[b], p.Tk) : p.Tk;
 
@@ -227,7 +227,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const cv_attn_params p) {
 
 extern "C" int cv_attention(const cv_attn_params* pp, void* stream) {
   if (!pp) return CV_ERR_ARG;
-  const cv_attn_params& p = *pp;
+  cv_attn_params p = *pp;
+  if (p.q_hs == 0) p.q_hs = 64;
+  if (p.k_hs == 0) p.k_hs = 64;
+  if ((p.q_hs & 7) || (p.k_hs & 7)) return CV_ERR_ARG;
   if (p.dtype != CV_BF16 && p.dtype != CV_F16) return CV_ERR_UNSUPPORTED;
   if (p.B <= 0 || p.H <= 0 || p.Hkv <= 0 || (p.H % p.Hkv) || p.Tq <= 0 || p.Tk <= 0) return CV_ERR_ARG;
   if (!p.q || !p.k || !p.vt || !p.out) return CV_ERR_ARG;

@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void embedding_kernel(const float* table, cons
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)rows * d4; i += (int64_t)gridDim.x * 256) {
     const int r = (int)(i / d4), c = (int)(i - (int64_t)r * d4) * 4;
     const int id = idx[r];
+    if (id == -2) continue;  // -2: leave the row untouched (multi-table assembly); -1: zero row
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (id >= 0) v = *(const float4*)(table + (int64_t)id * dim + c);
     st4<DT>(out, (int64_t)r * ldo + c, v.x, v.y, v.z, v.w);

@@ -1,0 +1,612 @@
+// LLM decode-step kernels for gfx950: skinny MFMA GEMM over pre-packed weights (HBM-bound weight streaming),
+// RMSNorm with split-K slab reduction, RoPE + KV append, single-query GQA attention, on-device RAS sampling.
+#include "cv_device.h"
+
+namespace {
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 nt_load16(const uint4* p) {
+  const u32x4_t v = __builtin_nontemporal_load((const u32x4_t*)p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// =========================================================================================== weight packing
+// packed[(tile * nks + ks) * 64 + lane][j] = W[src_row(tile*16 + (lane&15))][ks*32 + 8*(lane>>4) + j]
+__global__ __launch_bounds__(256) void pack_skinny_kernel(const uint16_t* W, uint16_t* Wp, int N, int K, int ntiles, int interleave) {
+  const int nks = K >> 5;
+  const int64_t total = (int64_t)ntiles * nks * 64;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int lane = (int)(i & 63);
+    const int64_t t = i >> 6;
+    const int ks = (int)(t % nks), tile = (int)(t / nks);
+    int row = tile * 16 + (lane & 15);
+    if (interleave) {
+      // packed tile 2j = gate rows [16j,16j+16), tile 2j+1 = up rows N/2 + [16j,16j+16)
+      const int j = tile >> 1;
+      row = ((tile & 1) ? (N >> 1) : 0) + j * 16 + (lane & 15);
+    }
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < N) v = *(const uint4*)(W + (int64_t)row * K + ks * 32 + 8 * (lane >> 4));
+    *(uint4*)(Wp + i * 8) = v;
+  }
+}
+
+// =========================================================================================== skinny GEMM
+template <int DT, int TPW>
+__global__ __launch_bounds__(256) void skinny_kernel(const cv_skinny_params p) {
+  __shared__ float red[4][TPW][64][4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int nks = p.K >> 5;
+  const int per = (nks + p.ksplit - 1) / p.ksplit;
+  const int kb = blockIdx.y * per, ke = min(nks, kb + per);
+  const int cnt = max(ke - kb, 0), pw = (cnt + 3) >> 2;
+  const int w0 = kb + wid * pw, w1 = min(ke, w0 + pw);
+  const int tile0 = blockIdx.x * TPW;
+
+  const uint16_t* Arow = (const uint16_t*)p.A + (int64_t)(lane & 15) * p.lda + 8 * (lane >> 4);
+  const uint4* Wt[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) Wt[t] = (const uint4*)p.Wp + (int64_t)(tile0 + t) * nks * 64 + lane;
+
+  f32x4_t acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int U = 8;
+  for (int ks = w0; ks < w1; ks += U) {
+    uint4 a[U], w[TPW][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = ks + u < w1;
+      a[u] = ok ? *(const uint4*)(Arow + (ks + u) * 32) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+        w[t][u] = ok ? nt_load16(Wt[t] + (int64_t)(ks + u) * 64) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) acc[t] = mfma_block<DT>(w[t][u], a[u], acc[t]);
+  }
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    red[wid][t][lane][0] = acc[t][0]; red[wid][t][lane][1] = acc[t][1];
+    red[wid][t][lane][2] = acc[t][2]; red[wid][t][lane][3] = acc[t][3];
+  }
+  __syncthreads();
+  if (wid != 0) return;
+  float v[TPW][4];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[t][r] = red[0][t][lane][r] + red[1][t][lane][r] + red[2][t][lane][r] + red[3][t][lane][r];
+
+  const int m = lane & 15, g = lane >> 4;
+  if (m >= p.M) return;
+  if (p.mode == 2) {
+    if constexpr (TPW == 2) {
+      const int nb = tile0 * 16 + 4 * g;          // gate tile columns in packed order
+      const int hcol = (tile0 >> 1) * 16 + 4 * g;  // output column
+      float h[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float gt = v[0][r], up = v[1][r];
+        if (p.bias) { gt += p.bias[nb + r]; up += p.bias[nb + 16 + r]; }
+        h[r] = act_silu(gt) * up;
+      }
+      uint2 u;
+      u.x = pack2<DT>(h[0], h[1]);
+      u.y = pack2<DT>(h[2], h[3]);
+      *(uint2*)((uint16_t*)p.out_act + (int64_t)m * p.ldoa + hcol) = u;
+    }
+    return;
+  }
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int nb = (tile0 + t) * 16 + 4 * g;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = nb + r;
+      if (n >= p.N) continue;
+      float o = v[t][r];
+      if (p.bias && blockIdx.y == 0) o += p.bias[n];
+      if (p.mode == 1) p.out_f32[(int64_t)m * p.ldo + n] += o;
+      else p.out_f32[(int64_t)blockIdx.y * p.slab_stride + (int64_t)m * p.ldo + n] = o;
+    }
+  }
+}
+
+// =========================================================================================== rmsnorm + slab reduce
+template <int DT>
+__global__ __launch_bounds__(256) void rmsnorm_reduce_kernel(float* x, int ldx, const float* slabs, int nslab, int64_t slab_stride,
+                                                             int ld_slab, const float* gamma, float eps, void* xn, int ldxn, int dim) {
+  __shared__ float wsum[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  float* xr = x + (int64_t)row * ldx;
+  const int nv = dim >> 2;
+  float4 v[4];  // dim <= 4096
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 256 + tid;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < nv) {
+      v[i] = *(const float4*)(xr + c * 4);
+      for (int s = 0; s < nslab; ++s) {
+        const float4 q = *(const float4*)(slabs + s * slab_stride + (int64_t)row * ld_slab + c * 4);
+        v[i].x += q.x; v[i].y += q.y; v[i].z += q.z; v[i].w += q.w;
+      }
+      if (nslab > 0) *(float4*)(xr + c * 4) = v[i];
+      ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    }
+  }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) wsum[tid >> 6] = ss;
+  __syncthreads();
+  const float tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  const float rstd = rsqrtf(tot / (float)dim + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 256 + tid;
+    if (c >= nv) continue;
+    const float4 gm = *(const float4*)(gamma + c * 4);
+    const float o0 = v[i].x * rstd * gm.x, o1 = v[i].y * rstd * gm.y, o2 = v[i].z * rstd * gm.z, o3 = v[i].w * rstd * gm.w;
+    if constexpr (DT == CV_F32) {
+      *(float4*)((float*)xn + (int64_t)row * ldxn + c * 4) = make_float4(o0, o1, o2, o3);
+    } else {
+      uint2 u;
+      u.x = pack2<DT>(o0, o1);
+      u.y = pack2<DT>(o2, o3);
+      *(uint2*)((uint16_t*)xn + (int64_t)row * ldxn + c * 4) = u;
+    }
+  }
+}
+
+// =========================================================================================== RoPE + KV append
+template <int DT>
+__global__ __launch_bounds__(256) void rope_append_kernel(const float* qkv, int ldqkv, const int32_t* pos_base, int rows_per_seq,
+                                                          int Hq, int Hkv, const float* inv_freq, uint16_t* q_out, int ldq,
+                                                          uint16_t* kcache, uint16_t* vtcache, int ctx_max) {
+  const int r = blockIdx.x;
+  const int b = r / rows_per_seq;
+  const int pos = pos_base[b] + (r - b * rows_per_seq);
+  const float* row = qkv + (int64_t)r * ldqkv;
+  const int nq = Hq * 32, nk = Hkv * 32, nvv = Hkv * 64;
+  for (int i = threadIdx.x; i < nq + nk + nvv; i += 256) {
+    if (i < nq + nk) {
+      const bool isq = i < nq;
+      const int j = isq ? i : i - nq;
+      const int h = j >> 5, d = j & 31;
+      const float* src = row + (isq ? 0 : Hq * 64) + h * 64;
+      const float x1 = src[d], x2 = src[d + 32];
+      float sn, cs;
+      sincosf((float)pos * inv_freq[d], &sn, &cs);
+      const float o1 = x1 * cs - x2 * sn, o2 = x2 * cs + x1 * sn;
+      if (isq) {
+        q_out[(int64_t)r * ldq + h * 64 + d] = Elem16<DT>::from_f32(o1);
+        q_out[(int64_t)r * ldq + h * 64 + d + 32] = Elem16<DT>::from_f32(o2);
+      } else if (pos < ctx_max) {
+        uint16_t* kd = kcache + (((int64_t)b * Hkv + h) * ctx_max + pos) * 64;
+        kd[d] = Elem16<DT>::from_f32(o1);
+        kd[d + 32] = Elem16<DT>::from_f32(o2);
+      }
+    } else if (pos < ctx_max) {
+      const int j = i - nq - nk;
+      const int h = j >> 6, d = j & 63;
+      vtcache[(((int64_t)b * Hkv + h) * 64 + d) * ctx_max + pos] = Elem16<DT>::from_f32(row[(Hq + Hkv) * 64 + j]);
+    }
+  }
+}
+
+// =========================================================================================== decode attention
+constexpr float NEG_BIG = -1e30f;
+
+template <int DT>
+__global__ __launch_bounds__(256) void decode_attn_kernel(const uint16_t* q, int ldq, const uint16_t* kcache, const uint16_t* vtcache,
+                                                          const int32_t* ctx_len, int ctx_add, uint16_t* out, int ldo, int Hq, int Hkv,
+                                                          int ctx_max, float scale) {
+  __shared__ float s_m[4][16], s_l[4][16];
+  __shared__ float s_o[4][64][17];  // [wave][d][query col] (+1 pad)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lq = lane & 15, lg = lane >> 4;
+  const int hk = blockIdx.x, b = blockIdx.y;
+  const int G = Hq / Hkv;  // query heads per kv head (<= 16)
+  const int ctx = min(ctx_len[b] + ctx_add, ctx_max);
+  const uint16_t* Kb = kcache + ((int64_t)b * Hkv + hk) * ctx_max * 64;
+  const uint16_t* Vb = vtcache + ((int64_t)b * Hkv + hk) * 64 * ctx_max;
+
+  // Q fragments: column lq = query head hk*G + lq (zero beyond the group)
+  uint4 qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    qf[ks] = make_uint4(0, 0, 0, 0);
+    if (lq < G) qf[ks] = *(const uint4*)(q + (int64_t)b * ldq + (hk * G + lq) * 64 + (ks * 4 + lg) * 8);
+  }
+  f32x4_t oacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) oacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float mrun = NEG_BIG, lrun = 0.f;
+  const float sc = scale * 1.4426950408889634f;
+  const int ntiles = (ctx + 63) >> 6;
+
+  for (int t = wid; t < ntiles; t += 4) {
+    const int j0 = t << 6;
+    f32x4_t sacc[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int key = j0 + kt * 16 + lq;
+      uint4 k0 = make_uint4(0, 0, 0, 0), k1 = k0;
+      if (key < ctx) {
+        k0 = *(const uint4*)(Kb + (int64_t)key * 64 + lg * 8);
+        k1 = *(const uint4*)(Kb + (int64_t)key * 64 + 32 + lg * 8);
+      }
+      f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      a = mfma_block<DT>(k0, qf[0], a);
+      a = mfma_block<DT>(k1, qf[1], a);
+      sacc[kt] = a;
+    }
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = j0 + kt * 16 + 4 * lg + r;
+        const float v = j < ctx ? sacc[kt][r] * sc : NEG_BIG;
+        sacc[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mnew = fmaxf(mrun, mx);
+    const float alpha = exp2f(mrun - mnew);
+    mrun = mnew;
+    float ls = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = exp2f(sacc[kt][r] - mnew);
+        sacc[kt][r] = e;
+        ls += e;
+      }
+    lrun = lrun * alpha + ls;
+    uint4 pf[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      pf[s2].x = pack2<DT>(sacc[2 * s2][0], sacc[2 * s2][1]);
+      pf[s2].y = pack2<DT>(sacc[2 * s2][2], sacc[2 * s2][3]);
+      pf[s2].z = pack2<DT>(sacc[2 * s2 + 1][0], sacc[2 * s2 + 1][1]);
+      pf[s2].w = pack2<DT>(sacc[2 * s2 + 1][2], sacc[2 * s2 + 1][3]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      oacc[dt][0] *= alpha; oacc[dt][1] *= alpha; oacc[dt][2] *= alpha; oacc[dt][3] *= alpha;
+      const uint16_t* vrow = Vb + (int64_t)(dt * 16 + lq) * ctx_max + j0 + 4 * lg;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        // keys j0 + 32 s2 + 4 lg + {0..3} and +16: the cache is zero-initialised, stale entries beyond ctx are finite
+        // and meet P == 0; guard only the buffer end
+        uint2 lo = make_uint2(0, 0), hi = lo;
+        const int kk = j0 + 32 * s2 + 4 * lg;
+        if (kk + 4 <= ctx_max) lo = *(const uint2*)(vrow + 32 * s2);
+        if (kk + 20 <= ctx_max) hi = *(const uint2*)(vrow + 32 * s2 + 16);
+        oacc[dt] = mfma_block<DT>(make_uint4(lo.x, lo.y, hi.x, hi.y), pf[s2], oacc[dt]);
+      }
+    }
+  }
+  // ---- merge the four waves (log-sum-exp)
+  float l = lrun;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (lg == 0) { s_m[wid][lq] = mrun; s_l[wid][lq] = l; }
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_o[wid][dt * 16 + 4 * lg + r][lq] = oacc[dt][r];
+  __syncthreads();
+  // thread -> (query col c = tid / 16 < 16, 4 d values)
+  const int c = tid >> 4, d0 = (tid & 15) * 4;
+  if (c < G) {
+    const float m0 = s_m[0][c], m1 = s_m[1][c], m2 = s_m[2][c], m3 = s_m[3][c];
+    const float mm = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    const float w0 = exp2f(m0 - mm), w1 = exp2f(m1 - mm), w2 = exp2f(m2 - mm), w3 = exp2f(m3 - mm);
+    const float lt = s_l[0][c] * w0 + s_l[1][c] * w1 + s_l[2][c] * w2 + s_l[3][c] * w3;
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      o[r] = (s_o[0][d0 + r][c] * w0 + s_o[1][d0 + r][c] * w1 + s_o[2][d0 + r][c] * w2 + s_o[3][d0 + r][c] * w3) * inv;
+    uint2 u;
+    u.x = pack2<DT>(o[0], o[1]);
+    u.y = pack2<DT>(o[2], o[3]);
+    *(uint2*)(out + (int64_t)b * ldo + (hk * G + c) * 64 + d0) = u;
+  }
+}
+
+// =========================================================================================== sampling
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
+    const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += W0;
+    k.y += W1;
+  }
+  return c;
+}
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+struct BestKV { float v; int i; };
+__device__ __forceinline__ BestKV better(BestKV a, BestKV b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
+
+constexpr int SV_PER = 32;  // values per thread -> V <= 8192
+
+__global__ __launch_bounds__(256) void sample_kernel(const cv_sample_params p) {
+  __shared__ float s_red[4];
+  __shared__ BestKV s_best[4];
+  __shared__ float s_candp[64];
+  __shared__ int s_candi[64];
+  __shared__ float s_scan[256];
+  __shared__ int s_flag[4];   // [0] need_fallback, [1] token, [2] done
+  __shared__ float s_u2;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (p.finished[b] != 0) return;
+  const float* lg = p.logits + (int64_t)b * p.ldl;
+  const int V = p.V;
+
+  float v[SV_PER];
+  float mx = NEG_BIG;
+#pragma unroll
+  for (int j = 0; j < SV_PER; ++j) {
+    const int i = tid + 256 * j;
+    v[j] = i < V ? lg[i] : NEG_BIG;
+    mx = fmaxf(mx, v[j]);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) s_red[wid] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  __syncthreads();
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < SV_PER; ++j) {
+    v[j] = (tid + 256 * j) < V ? __expf(v[j] - mx) : 0.f;
+    sum += v[j];
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) s_red[wid] = sum;
+  __syncthreads();
+  sum = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int j = 0; j < SV_PER; ++j) v[j] *= inv;  // probabilities
+
+  // ---- nucleus candidates: descending prob, stable (lower index first); take while cum < top_p and n < top_k
+  uint32_t taken = 0;
+  int ncand = 0;
+  float cum = 0.f;
+  const int top_k = min(p.top_k, 64);
+  while (ncand < top_k && cum < p.top_p) {
+    BestKV best{-1.f, 0x7fffffff};
+#pragma unroll
+    for (int j = 0; j < SV_PER; ++j)
+      if (!((taken >> j) & 1u) && (tid + 256 * j) < V && v[j] > best.v) best = BestKV{v[j], tid + 256 * j};
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      BestKV other{__shfl_xor(best.v, o, 64), __shfl_xor(best.i, o, 64)};
+      best = better(best, other);
+    }
+    if (lane == 0) s_best[wid] = best;
+    __syncthreads();
+    best = better(better(s_best[0], s_best[1]), better(s_best[2], s_best[3]));
+    __syncthreads();
+    if ((best.i & 255) == tid) taken |= 1u << (best.i >> 8);
+    if (tid == 0) { s_candp[ncand] = best.v; s_candi[ncand] = best.i; }
+    cum += best.v;
+    ++ncand;
+  }
+  __syncthreads();
+
+  // ---- trials (llm.py:813-820): redraw while EOS is sampled before min_len
+  const int step = p.step[b];
+  const bool ignore_eos = step < p.min_len[b];
+  const int n_em = p.n_emitted[b];
+  int token = -1;
+  int status = 0;
+  for (int trial = 0;; ++trial) {
+    if (tid == 0) {
+      float u1, u2;
+      if (p.uniforms) {
+        u1 = p.uniforms[((int64_t)b * (p.max_trials + 1) + trial) * 2];
+        u2 = p.uniforms[((int64_t)b * (p.max_trials + 1) + trial) * 2 + 1];
+      } else {
+        const uint4 r = philox4x32_10(make_uint4((uint32_t)step, (uint32_t)b, (uint32_t)trial, 0u),
+                                      make_uint2((uint32_t)p.seed, (uint32_t)(p.seed >> 32)));
+        u1 = u01(r.x);
+        u2 = u01(r.y);
+      }
+      // nucleus draw: inverse CDF over the candidate probabilities (renormalised)
+      const float target = u1 * cum;
+      float c = 0.f;
+      int pick = ncand - 1;
+      for (int i = 0; i < ncand; ++i) {
+        c += s_candp[i];
+        if (c > target) { pick = i; break; }
+      }
+      int tok = s_candi[pick];
+      // repetition check over the last win_size emitted tokens (utils/common.py:111-113)
+      int rep = 0;
+      const int w0 = max(0, n_em - p.win_size);
+      for (int i = w0; i < n_em; ++i) rep += (p.out_tokens[(int64_t)b * p.out_ld + i] == tok);
+      s_flag[0] = ((float)rep >= (float)p.win_size * p.tau_r) ? 1 : 0;
+      s_flag[1] = tok;
+      s_u2 = u2;
+    }
+    __syncthreads();
+    if (s_flag[0]) {
+      // random_sampling over the full distribution: thread t owns the contiguous range [t*chunk, (t+1)*chunk)
+      const int chunk = (V + 255) / 256;
+      const int i0 = tid * chunk, i1 = min(V, i0 + chunk);
+      float loc = 0.f;
+      for (int i = i0; i < i1; ++i) loc += __expf(lg[i] - mx) * inv;
+      s_scan[tid] = loc;
+      __syncthreads();
+      if (tid == 0) {
+        float tot = 0.f;
+        for (int i = 0; i < 256; ++i) tot += s_scan[i];
+        const float target = s_u2 * tot;
+        float c = 0.f;
+        int owner = 255;
+        for (int i = 0; i < 256; ++i) {
+          if (c + s_scan[i] > target) { owner = i; break; }
+          c += s_scan[i];
+        }
+        // walk the owner's range
+        const int j0 = owner * chunk, j1 = min(V, j0 + chunk);
+        int tok = max(j1 - 1, 0);
+        for (int i = j0; i < j1; ++i) {
+          c += __expf(lg[i] - mx) * inv;
+          if (c > target) { tok = i; break; }
+        }
+        s_flag[1] = tok;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      int done = 1;
+      if (ignore_eos && s_flag[1] == p.eos) {
+        done = 0;
+        if (trial + 1 > p.max_trials) done = 2;  // sampling stalled
+      }
+      s_flag[2] = done;
+    }
+    __syncthreads();
+    const int done = s_flag[2];
+    token = s_flag[1];
+    __syncthreads();
+    if (done) { status = done; break; }
+  }
+
+  // ---- bookkeeping (llm.py:866-874)
+  if (p.forced) {
+    const int f = (n_em < p.forced_ld) ? p.forced[(int64_t)b * p.forced_ld + n_em] : -2;
+    if (f >= 0) { token = f; status = 1; }
+    else if (f == -2) token = p.eos;  // forced list exhausted -> stop
+  }
+  bool emit = false;
+  int fin = 0;
+  if (status == 2) fin = 3;
+  else if (token == p.eos) fin = 1;
+  else if (token < p.eos) emit = true;
+  if (emit && n_em >= p.out_ld) { emit = false; fin = 2; }
+  if (emit) {
+    const float* e = p.emb_table + (int64_t)token * p.emb_dim;
+    for (int i = tid; i < p.emb_dim; i += 256) p.x[(int64_t)b * p.ldx + i] = e[i];
+  }
+  if (tid == 0) {
+    if (emit) {
+      p.out_tokens[(int64_t)b * p.out_ld + n_em] = token;
+      p.n_emitted[b] = n_em + 1;
+    }
+    p.step[b] = step + 1;
+    p.pos[b] += 1;
+    if (!fin && step + 1 >= p.max_len[b]) fin = 2;
+    if (fin) p.finished[b] = fin;
+  }
+}
+
+}  // namespace
+
+#define DISPATCH_16(dt, CALL)                                   \
+  switch (dt) {                                                 \
+    case CV_BF16: { constexpr int DT = CV_BF16; CALL; } break;  \
+    case CV_F16: { constexpr int DT = CV_F16; CALL; } break;    \
+    default: return CV_ERR_UNSUPPORTED;                         \
+  }
+
+extern "C" int cv_sizeof_skinny_params(void) { return (int)sizeof(cv_skinny_params); }
+extern "C" int cv_sizeof_sample_params(void) { return (int)sizeof(cv_sample_params); }
+
+extern "C" int cv_pack_skinny(const void* W, void* Wp, int32_t N, int32_t K, int32_t interleave, void* stream) {
+  if (!W || !Wp || N <= 0 || K <= 0 || (K & 31)) return CV_ERR_ARG;
+  if (interleave && (N & 31)) return CV_ERR_ARG;
+  const int ntiles = (N + 15) / 16;
+  const int64_t total = (int64_t)ntiles * (K >> 5) * 64;
+  const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipLaunchKernelGGL(pack_skinny_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)W, (uint16_t*)Wp, N, K,
+                     ntiles, interleave);
+  CV_CHECK_LAUNCH();
+  return CV_OK;
+}
+
+extern "C" int cv_skinny_gemm(const cv_skinny_params* pp, void* stream) {
+  if (!pp) return CV_ERR_ARG;
+  cv_skinny_params p = *pp;
+  if (p.M <= 0 || p.M > 16 || p.N <= 0 || p.K <= 0 || (p.K & 31) || !p.A || !p.Wp || (p.lda & 7)) return CV_ERR_ARG;
+  if (p.ksplit <= 0) p.ksplit = 1;
+  const int ntiles = (p.N + 15) / 16;
+  hipStream_t st = (hipStream_t)stream;
+  if (p.mode == 2) {
+    if (p.ksplit != 1 || (ntiles & 1) || !p.out_act || (p.ldoa & 3)) return CV_ERR_ARG;
+    dim3 grid(ntiles / 2, 1);
+    DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, 2>), grid, dim3(256), 0, st, p));
+  } else {
+    if (!p.out_f32) return CV_ERR_ARG;
+    if (p.mode == 1 && p.ksplit != 1) return CV_ERR_ARG;
+    dim3 grid(ntiles, p.ksplit);
+    DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, 1>), grid, dim3(256), 0, st, p));
+  }
+  CV_CHECK_LAUNCH();
+  return CV_OK;
+}
+
+extern "C" int cv_rmsnorm_reduce(float* x, int32_t ldx, const float* slabs, int32_t nslab, int64_t slab_stride, int32_t ld_slab,
+                                 const float* gamma, float eps, void* xn, int32_t ldxn, int32_t dtype, int32_t rows, int32_t dim, void* stream) {
+  if (!x || !gamma || !xn || rows <= 0 || dim <= 0 || (dim & 3) || dim > 4096 || (ldx & 3) || (ldxn & 3)) return CV_ERR_ARG;
+  if (nslab > 0 && (!slabs || (ld_slab & 3) || (slab_stride & 3))) return CV_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case CV_F32: hipLaunchKernelGGL(rmsnorm_reduce_kernel<CV_F32>, dim3(rows), dim3(256), 0, st, x, ldx, slabs, nslab, slab_stride, ld_slab, gamma, eps, xn, ldxn, dim); break;
+    case CV_BF16: hipLaunchKernelGGL(rmsnorm_reduce_kernel<CV_BF16>, dim3(rows), dim3(256), 0, st, x, ldx, slabs, nslab, slab_stride, ld_slab, gamma, eps, xn, ldxn, dim); break;
+    case CV_F16: hipLaunchKernelGGL(rmsnorm_reduce_kernel<CV_F16>, dim3(rows), dim3(256), 0, st, x, ldx, slabs, nslab, slab_stride, ld_slab, gamma, eps, xn, ldxn, dim); break;
+    default: return CV_ERR_ARG;
+  }
+  CV_CHECK_LAUNCH();
+  return CV_OK;
+}
+
+extern "C" int cv_rope_append(const float* qkv, int32_t ldqkv, const int32_t* pos_base, int32_t rows, int32_t rows_per_seq,
+                              int32_t Hq, int32_t Hkv, const float* inv_freq, void* q_out, int32_t ldq, void* kcache, void* vtcache,
+                              int32_t ctx_max, int32_t dtype, void* stream) {
+  if (!qkv || !pos_base || !inv_freq || !q_out || !kcache || !vtcache || rows <= 0 || rows_per_seq <= 0 || Hq <= 0 || Hkv <= 0) return CV_ERR_ARG;
+  DISPATCH_16(dtype, hipLaunchKernelGGL(rope_append_kernel<DT>, dim3(rows), dim3(256), 0, (hipStream_t)stream, qkv, ldqkv, pos_base,
+                                        rows_per_seq, Hq, Hkv, inv_freq, (uint16_t*)q_out, ldq, (uint16_t*)kcache, (uint16_t*)vtcache, ctx_max));
+  CV_CHECK_LAUNCH();
+  return CV_OK;
+}
+
+extern "C" int cv_decode_attention(const void* q, int32_t ldq, const void* kcache, const void* vtcache, const int32_t* ctx_len,
+                                   int32_t ctx_add, void* out, int32_t ldo, int32_t B, int32_t Hq, int32_t Hkv, int32_t ctx_max,
+                                   float scale, int32_t dtype, void* stream) {
+  if (!q || !kcache || !vtcache || !ctx_len || !out || B <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || Hq / Hkv > 16) return CV_ERR_ARG;
+  if ((ldq & 7) || (ldo & 3) || (ctx_max & 7)) return CV_ERR_ARG;
+  dim3 grid(Hkv, B);
+  DISPATCH_16(dtype, hipLaunchKernelGGL(decode_attn_kernel<DT>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)q, ldq,
+                                        (const uint16_t*)kcache, (const uint16_t*)vtcache, ctx_len, ctx_add, (uint16_t*)out, ldo, Hq, Hkv,
+                                        ctx_max, scale));
+  CV_CHECK_LAUNCH();
+  return CV_OK;
+}
+
+extern "C" int cv_sample_ras(const cv_sample_params* pp, void* stream) {
+  if (!pp) return CV_ERR_ARG;
+  const cv_sample_params& p = *pp;
+  if (!p.logits || p.V <= 0 || p.V > 256 * SV_PER || p.B <= 0 || !p.min_len || !p.max_len || !p.step || !p.pos || !p.n_emitted ||
+      !p.finished || !p.out_tokens || !p.emb_table || !p.x || p.top_k <= 0)
+    return CV_ERR_ARG;
+  hipLaunchKernelGGL(sample_kernel, dim3(p.B), dim3(256), 0, (hipStream_t)stream, p);
+  CV_CHECK_LAUNCH();
+  return CV_OK;
+}

@@ -1,0 +1,340 @@
+"""Speech-token LM on MI355X — host side of the drop-in for the reference's ``Qwen2LM`` + ``Qwen2Encoder``
+(/root/reference/cosyvoice/llm/llm.py:743-874).  Same state-dict key names (HF Qwen2 names under
+``llm.model.*``), same generator ``inference(...)`` yielding python ints.
+
+Design (MI355X-first, not the reference's 4-graphs-per-layer path, llm/qwen2_5.py:97-179):
+  * prefill: generic MFMA GEMMs + causal GQA flash attention over the freshly written KV cache;
+  * decode: ONE hipGraph per step for the whole model: per layer
+      rmsnorm(+split-K slab reduce) -> skinny QKV GEMM -> RoPE + KV append -> single-query GQA attention ->
+      skinny o_proj (in-place residual) -> rmsnorm -> skinny gate/up + SwiGLU -> skinny down (split-K slabs),
+    then final norm -> 6564-way head -> on-device RAS sampling, which also writes the next input embedding.
+    Positions, cache lengths, EOS / min-len / max-len state all live on the device: the host only replays
+    the graph and polls the token buffer (keeps the llm_job thread semantics of cli/model.py:116-128).
+  * weights: 16-bit, pre-packed at load into MFMA B-fragment order for the decode path (1 KiB per wave-load).
+Batching: B <= 16 sequences per step share every weight read (the reference is batch-1).
+"""
+import math
+from typing import Dict, Generator, List, Optional
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .config import LlmConfig
+
+P_ = "llm.model.model."
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class Qwen2LM:
+    DOWN_KSPLIT = 4
+
+    def __init__(self, cfg: Optional[LlmConfig] = None, dtype: torch.dtype = torch.bfloat16, device: str = "cuda",
+                 max_batch: int = 8, ctx_max: int = 1024, max_out: int = 2048, top_p: float = 0.8, top_k: int = 25,
+                 win_size: int = 10, tau_r: float = 0.1):
+        self.cfg = cfg or LlmConfig.full()
+        self.dtype, self.device = dtype, torch.device(device)
+        assert max_batch <= 16 and ctx_max % 64 == 0
+        self.max_batch, self.ctx_max, self.max_out = max_batch, ctx_max, max_out
+        self.top_p, self.top_k, self.win_size, self.tau_r = top_p, top_k, win_size, tau_r
+        self.speech_token_size = self.cfg.speech_token_size
+        self.sos_eos, self.task_id = 0, 1
+        self.fp16 = False
+        self.seed = 0
+        self.use_graph = True
+        self._loaded = False
+        self._graphs: Dict[int, ops.Graph] = {}
+        self._prefill_ws: Dict[tuple, dict] = {}
+
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    def half(self):
+        return self
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd, strict: bool = False):
+        cfg, dt, dev = self.cfg, self.dtype, self.device
+        f32 = lambda k: sd[k].detach().to(device=dev, dtype=torch.float32).contiguous()
+        w16 = lambda t: t.detach().to(torch.float32).to(device=dev, dtype=dt).contiguous()
+        I = cfg.intermediate_size
+        assert I % 16 == 0 and cfg.hidden_size % 32 == 0 and cfg.head_dim == 64
+        self.layers = []
+        for i in range(cfg.num_layers):
+            lp = f"{P_}layers.{i}."
+            wqkv = torch.cat([sd[lp + "self_attn.q_proj.weight"], sd[lp + "self_attn.k_proj.weight"], sd[lp + "self_attn.v_proj.weight"]], 0)
+            bqkv = torch.cat([sd[lp + "self_attn.q_proj.bias"], sd[lp + "self_attn.k_proj.bias"], sd[lp + "self_attn.v_proj.bias"]], 0)
+            g, u = sd[lp + "mlp.gate_proj.weight"].float(), sd[lp + "mlp.up_proj.weight"].float()
+            # prefill GEMM wants [gate16 | up16] interleaved 16-row blocks (SwiGLU epilogue pairs adjacent MFMA tiles)
+            gu = torch.stack([g.view(I // 16, 16, -1), u.view(I // 16, 16, -1)], dim=1).reshape(2 * I, -1)
+            lay = dict(wqkv=w16(wqkv), bqkv=bqkv.detach().to(device=dev, dtype=torch.float32).contiguous(),
+                       wo=w16(sd[lp + "self_attn.o_proj.weight"]), wgu=w16(gu), wdown=w16(sd[lp + "mlp.down_proj.weight"]),
+                       g_in=f32(lp + "input_layernorm.weight"), g_post=f32(lp + "post_attention_layernorm.weight"))
+            lay["p_qkv"] = ops.pack_skinny(lay["wqkv"])
+            lay["p_o"] = ops.pack_skinny(lay["wo"])
+            lay["p_gu"] = ops.pack_skinny(w16(torch.cat([g, u], 0)), interleave=True)
+            lay["p_down"] = ops.pack_skinny(lay["wdown"])
+            self.layers.append(lay)
+        self.g_final = f32(f"{P_}norm.weight")
+        self.embed_tokens = f32(f"{P_}embed_tokens.weight")
+        self.llm_embedding = f32("llm_embedding.weight")
+        self.speech_embedding = f32("speech_embedding.weight")
+        self.dec_b = f32("llm_decoder.bias")
+        self.p_dec = ops.pack_skinny(w16(sd["llm_decoder.weight"]))
+        inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, cfg.head_dim, 2, dtype=torch.float32) / cfg.head_dim))
+        self.inv_freq = inv.to(dev).contiguous()
+        self._alloc_state()
+        self._loaded = True
+        return self
+
+    def _alloc_state(self):
+        cfg, dt, dev = self.cfg, self.dtype, self.device
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        qkv_dim = cfg.q_dim + 2 * cfg.kv_dim
+        z = lambda *s, dtype=torch.float32: torch.zeros(*s, device=dev, dtype=dtype)
+        self.Vpad = _round_up(cfg.out_vocab, 16)
+        MB = self.max_batch
+        self.st = dict(x=z(16, H), xn=z(16, H, dtype=dt), qkv=z(16, qkv_dim), q=z(16, cfg.q_dim, dtype=dt),
+                       ao=z(16, cfg.q_dim, dtype=dt), h=z(16, I, dtype=dt), slabs=z(self.DOWN_KSPLIT, 16, H),
+                       logits=z(16, self.Vpad), pos=z(16, dtype=torch.int32), step=z(16, dtype=torch.int32),
+                       n_emitted=z(16, dtype=torch.int32), finished=z(16, dtype=torch.int32), min_len=z(16, dtype=torch.int32),
+                       max_len=z(16, dtype=torch.int32), out_tokens=z(16, self.max_out, dtype=torch.int32),
+                       forced=torch.full((16, self.max_out), -1, device=dev, dtype=torch.int32),
+                       uniforms=z(16, 101, 2))
+        self.kcache = [z(MB, cfg.num_kv_heads, self.ctx_max, 64, dtype=dt) for _ in range(cfg.num_layers)]
+        self.vtcache = [z(MB, cfg.num_kv_heads, 64, self.ctx_max, dtype=dt) for _ in range(cfg.num_layers)]
+
+    # ------------------------------------------------------------------ decode step (graph-capturable)
+    def _head_and_sample(self, B, use_forced, use_uniforms):
+        cfg, st = self.cfg, self.st
+        H = cfg.hidden_size
+        ops.skinny_gemm(st["xn"], self.p_dec, B, cfg.out_vocab, H, bias=self.dec_b, out_f32=st["logits"], ldo=self.Vpad)
+        p = L.SampleParams()
+        p.logits, p.ldl, p.V, p.B = st["logits"].data_ptr(), self.Vpad, cfg.out_vocab, B
+        p.eos, p.top_k, p.top_p, p.win_size, p.tau_r = cfg.speech_token_size, self.top_k, self.top_p, self.win_size, self.tau_r
+        p.seed = self.seed
+        p.uniforms = st["uniforms"].data_ptr() if use_uniforms else None
+        p.max_trials = 100
+        p.min_len, p.max_len = st["min_len"].data_ptr(), st["max_len"].data_ptr()
+        p.forced, p.forced_ld = (st["forced"].data_ptr() if use_forced else None), self.max_out
+        p.step, p.pos, p.n_emitted, p.finished = (st["step"].data_ptr(), st["pos"].data_ptr(), st["n_emitted"].data_ptr(),
+                                                  st["finished"].data_ptr())
+        p.out_tokens, p.out_ld = st["out_tokens"].data_ptr(), self.max_out
+        p.emb_table, p.emb_dim = self.speech_embedding.data_ptr(), H
+        p.x, p.ldx = st["x"].data_ptr(), H
+        ops.sample_ras(p)
+
+    def _decode_step(self, B, use_forced=False, use_uniforms=False):
+        cfg, st = self.cfg, self.st
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        qkv_dim = cfg.q_dim + 2 * cfg.kv_dim
+        KS = self.DOWN_KSPLIT
+        scale = 1.0 / math.sqrt(cfg.head_dim)
+        for li, lay in enumerate(self.layers):
+            if li == 0:
+                ops.rmsnorm_reduce(st["x"], lay["g_in"], cfg.rms_eps, st["xn"], B)
+            else:
+                ops.rmsnorm_reduce(st["x"], lay["g_in"], cfg.rms_eps, st["xn"], B, slabs=st["slabs"], nslab=KS, slab_stride=16 * H, ld_slab=H)
+            ops.skinny_gemm(st["xn"], lay["p_qkv"], B, qkv_dim, H, bias=lay["bqkv"], out_f32=st["qkv"], ldo=qkv_dim)
+            ops.rope_append(st["qkv"], st["pos"], B, 1, cfg.num_heads, cfg.num_kv_heads, self.inv_freq, st["q"], self.kcache[li],
+                            self.vtcache[li], self.ctx_max)
+            ops.decode_attention(st["q"], self.kcache[li], self.vtcache[li], st["pos"], 1, st["ao"], B, cfg.num_heads,
+                                 cfg.num_kv_heads, self.ctx_max, scale)
+            ops.skinny_gemm(st["ao"], lay["p_o"], B, H, cfg.q_dim, mode=1, out_f32=st["x"], ldo=H)
+            ops.rmsnorm_reduce(st["x"], lay["g_post"], cfg.rms_eps, st["xn"], B)
+            ops.skinny_gemm(st["xn"], lay["p_gu"], B, 2 * I, H, mode=2, out_act=st["h"], ldoa=I)
+            ops.skinny_gemm(st["h"], lay["p_down"], B, H, I, ksplit=KS, out_f32=st["slabs"], ldo=H, slab_stride=16 * H)
+        ops.rmsnorm_reduce(st["x"], self.g_final, cfg.rms_eps, st["xn"], B, slabs=st["slabs"], nslab=KS, slab_stride=16 * H, ld_slab=H)
+        self._head_and_sample(B, use_forced, use_uniforms)
+
+    def _step(self, B, use_forced, use_uniforms):
+        if not self.use_graph:
+            self._decode_step(B, use_forced, use_uniforms)
+            return
+        key = (B, use_forced, use_uniforms, self.seed)
+        g = self._graphs.get(key)
+        if g is None:
+            g = ops.Graph().capture(lambda: self._decode_step(B, use_forced, use_uniforms))
+            self._graphs[key] = g
+        g.launch()
+
+    # ------------------------------------------------------------------ prefill
+    def _prefill(self, B, Lp, use_forced, use_uniforms):
+        """Input embeddings already in ws['x'] (B*Lp, H) fp32.  Writes the KV caches for positions [0,Lp), leaves the
+        last position's hidden state in st['x'] and runs head + sampling (llm.py:861-866, first loop iteration)."""
+        cfg, dt, dev, st = self.cfg, self.dtype, self.device, self.st
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        qkv_dim = cfg.q_dim + 2 * cfg.kv_dim
+        ws = self._prefill_workspace(B, Lp)
+        rows = B * Lp
+        x = ws["x"]
+        st["pos"].zero_()
+        scale = 1.0 / math.sqrt(cfg.head_dim)
+        for li, lay in enumerate(self.layers):
+            ops.layernorm(x, lay["g_in"], None, cfg.rms_eps, rms=True, out_act=ws["xn"])
+            ops.linear(ws["xn"], lay["wqkv"], bias=lay["bqkv"], out_f32=ws["qkv"])
+            ops.rope_append(ws["qkv"], st["pos"], rows, Lp, cfg.num_heads, cfg.num_kv_heads, self.inv_freq, ws["q"], self.kcache[li],
+                            self.vtcache[li], self.ctx_max)
+            ops.attention(ws["q"], self.kcache[li], self.vtcache[li], ws["ao"], B=B, H=cfg.num_heads, Hkv=cfg.num_kv_heads, Tq=Lp,
+                          Tk=Lp, scale=scale, q_bs=Lp * cfg.q_dim, ldq=cfg.q_dim, k_bs=cfg.num_kv_heads * self.ctx_max * 64,
+                          k_hs=self.ctx_max * 64, ldk=64, vt_ld=self.ctx_max, o_bs=Lp * cfg.q_dim, ldo=cfg.q_dim, causal=True)
+            ops.linear(ws["ao"], lay["wo"], res=x, out_f32=x)
+            ops.layernorm(x, lay["g_post"], None, cfg.rms_eps, rms=True, out_act=ws["xn"])
+            ops.linear(ws["xn"], lay["wgu"], act=ops.ACT_SWIGLU, out_act=ws["h"])
+            ops.linear(ws["h"], lay["wdown"], res=x, out_f32=x)
+        # last position of every sequence -> decode state
+        st["x"][:B].copy_(x.view(B, Lp, H)[:, Lp - 1])
+        st["pos"][:B].fill_(Lp - 1)  # the sampler's +1 then makes pos = Lp = cache length
+        ops.rmsnorm_reduce(st["x"], self.g_final, cfg.rms_eps, st["xn"], B)
+        self._head_and_sample(B, use_forced, use_uniforms)
+
+    def _prefill_workspace(self, B, Lp):
+        key = (B, Lp)
+        if key not in self._prefill_ws:
+            cfg, dt, dev = self.cfg, self.dtype, self.device
+            rows = B * Lp
+            e = lambda *s, dtype=torch.float32: torch.empty(*s, device=dev, dtype=dtype)
+            self._prefill_ws[key] = dict(x=e(rows, cfg.hidden_size), xn=e(rows, cfg.hidden_size, dtype=dt),
+                                         qkv=e(rows, cfg.q_dim + 2 * cfg.kv_dim), q=e(rows, cfg.q_dim, dtype=dt),
+                                         ao=e(rows, cfg.q_dim, dtype=dt), h=e(rows, cfg.intermediate_size, dtype=dt),
+                                         idx=torch.empty(3, rows, device=dev, dtype=torch.int32))
+        return self._prefill_ws[key]
+
+    def _assemble_inputs(self, ws, texts, prompt_texts, prompt_speech, B, Lp):
+        """lm_input = [sos_eos, embed(prompt_text + text), task_id, speech_emb(prompt_speech)] (llm.py:837-852)."""
+        idx = ws["idx"].view(3, B, Lp)
+        idx.fill_(-2)
+        dev = self.device
+        for b in range(B):
+            t = torch.cat([prompt_texts[b].reshape(-1).to(dev), texts[b].reshape(-1).to(dev)]).to(torch.int32)
+            ps = prompt_speech[b].reshape(-1).to(dev, torch.int32)
+            lt, lps = t.numel(), ps.numel()
+            assert 1 + lt + 1 + lps == Lp, "batched prefill needs equal prompt lengths"
+            idx[2, b, 0] = self.sos_eos
+            idx[0, b, 1:1 + lt] = t
+            idx[2, b, 1 + lt] = self.task_id
+            idx[1, b, 2 + lt:] = ps
+        for k, table in enumerate((self.embed_tokens, self.speech_embedding, self.llm_embedding)):
+            ops.embedding(table, ws["idx"][k], ws["x"])
+
+    # ------------------------------------------------------------------ public API
+    @torch.no_grad()
+    def generate_batch(self, texts: List[torch.Tensor], prompt_texts: List[torch.Tensor], prompt_speech: List[torch.Tensor],
+                       forced: Optional[List[List[int]]] = None, uniforms: Optional[torch.Tensor] = None,
+                       max_token_text_ratio: float = 20, min_token_text_ratio: float = 2, steps_per_poll: int = 16,
+                       max_steps: Optional[int] = None) -> List[List[int]]:
+        """Run B sequences (equal prompt length) to completion; returns the emitted token lists."""
+        assert self._loaded
+        B = len(texts)
+        assert 1 <= B <= self.max_batch
+        st = self.st
+        Lp = 1 + prompt_texts[0].numel() + texts[0].numel() + 1 + prompt_speech[0].numel()
+        ws = self._prefill_workspace(B, Lp)
+        for k in ("step", "n_emitted", "finished"):
+            st[k].zero_()
+        st["finished"][B:].fill_(1)
+        mn = torch.zeros(16, dtype=torch.int32)
+        mx = torch.zeros(16, dtype=torch.int32)
+        for b in range(B):
+            tl = texts[b].numel()  # text_len - prompt_text_len (llm.py:855-856)
+            mn[b] = int(tl * min_token_text_ratio)
+            mx[b] = int(tl * max_token_text_ratio)
+            assert Lp + int(mx[b]) <= self.ctx_max, "ctx_max too small"
+        st["min_len"].copy_(mn)
+        st["max_len"].copy_(mx)
+        use_forced = forced is not None
+        if use_forced:
+            f = torch.full((16, self.max_out), -2, dtype=torch.int32)
+            for b in range(B):
+                f[b, :len(forced[b])] = torch.tensor(forced[b], dtype=torch.int32)
+            st["forced"].copy_(f)
+        use_uniforms = uniforms is not None
+        if use_uniforms:
+            st["uniforms"].copy_(uniforms.to(torch.float32))
+        self._assemble_inputs(ws, texts, prompt_texts, prompt_speech, B, Lp)
+        self._prefill(B, Lp, use_forced, use_uniforms)
+        limit = int(mx[:B].max()) if max_steps is None else max_steps
+        done_steps = 1
+        while done_steps < limit:
+            n = min(steps_per_poll, limit - done_steps)
+            for _ in range(n):
+                self._step(B, use_forced, use_uniforms)
+            done_steps += n
+            if bool((st["finished"][:B] != 0).all().item()):
+                break
+        fin = st["finished"][:B].cpu()
+        if bool((fin == 3).any()):
+            raise RuntimeError("sampling reaches max_trials 100 and still get eos when ignore_eos is True, check your input!")
+        ne = st["n_emitted"][:B].cpu()
+        toks = st["out_tokens"][:B].cpu()
+        return [toks[b, :int(ne[b])].tolist() for b in range(B)]
+
+    @torch.no_grad()
+    def inference(self, text, text_len, prompt_text, prompt_text_len, prompt_speech_token, prompt_speech_token_len, embedding,
+                  sampling: int = 25, max_token_text_ratio: float = 20, min_token_text_ratio: float = 2
+                  ) -> Generator[int, None, None]:
+        """Reference signature (llm.py:823-836).  Yields python ints as they become available (polled every 8 steps)."""
+        assert self._loaded
+        text_len += prompt_text_len  # the reference mutates text_len in place (llm.py:839)
+        st = self.st
+        B = 1
+        Lp = 1 + prompt_text.numel() + text.numel() + 1 + prompt_speech_token.numel()
+        ws = self._prefill_workspace(B, Lp)
+        for k in ("step", "n_emitted", "finished"):
+            st[k].zero_()
+        st["finished"][B:].fill_(1)
+        tl = text.numel()
+        min_len, max_len = int(tl * min_token_text_ratio), int(tl * max_token_text_ratio)
+        if Lp + max_len > self.ctx_max:
+            raise ValueError("ctx_max too small for this request")
+        st["min_len"].fill_(min_len)
+        st["max_len"].fill_(max_len)
+        self._assemble_inputs(ws, [text], [prompt_text], [prompt_speech_token], B, Lp)
+        self._prefill(B, Lp, False, False)
+        sent, steps = 0, 1
+        while True:
+            fin = int(st["finished"][0].item())
+            ne = int(st["n_emitted"][0].item())
+            if ne > sent:
+                for t in st["out_tokens"][0, sent:ne].tolist():
+                    yield t
+                sent = ne
+            if fin == 3:
+                raise RuntimeError("sampling reaches max_trials 100 and still get eos when ignore_eos is True, check your input!")
+            if fin != 0 or steps >= max_len:
+                break
+            n = min(8, max_len - steps)
+            for _ in range(n):
+                self._step(B, False, False)
+            steps += n
+
+    # teacher-forced log-probs for parity tests (not on the product path of tts())
+    @torch.no_grad()
+    def forced_logits(self, text, prompt_text, prompt_speech, forced: List[int]) -> torch.Tensor:
+        """Returns (len(forced)+1, V) log-softmax rows: prefill + one row per forced token (SURVEY.md H1 parity contract)."""
+        st = self.st
+        B = 1
+        Lp = 1 + prompt_text.numel() + text.numel() + 1 + prompt_speech.numel()
+        ws = self._prefill_workspace(B, Lp)
+        for k in ("step", "n_emitted", "finished"):
+            st[k].zero_()
+        st["finished"][B:].fill_(1)
+        st["min_len"].fill_(0)
+        st["max_len"].fill_(len(forced) + 8)
+        f = torch.full((16, self.max_out), -2, dtype=torch.int32)
+        f[0, :len(forced)] = torch.tensor(forced, dtype=torch.int32)
+        st["forced"].copy_(f)
+        self._assemble_inputs(ws, [text], [prompt_text], [prompt_speech], B, Lp)
+        out = []
+        self._prefill(B, Lp, True, False)
+        out.append(st["logits"][0, :self.cfg.out_vocab].clone())
+        for _ in range(len(forced)):
+            self._step(B, True, False)
+            out.append(st["logits"][0, :self.cfg.out_vocab].clone())
+        return torch.stack(out).log_softmax(dim=-1)

@@ -1,0 +1,166 @@
+"""Orchestrator — drop-in for the reference's ``CosyVoice2Model`` (/root/reference/cosyvoice/cli/model.py:295-424):
+per-request uuid state, LLM producer thread (``llm_job``), ``token2wav`` (flow -> HiFT with the streaming
+mel/source/speech caches and hamming cross-fade), ``tts`` generator yielding ``{'tts_speech': Tensor(1,S) cpu}``.
+
+The stage objects are the HIP-backed ``cosyvoice_amd.llm.Qwen2LM`` / ``flow.CausalMaskedDiffWithXvec`` /
+``hift.HiFTGenerator`` (they expose what the orchestrator touches, SURVEY.md §8b level 1), so
+``cosyvoice.cli`` code that builds a CosyVoice2Model keeps working with this class.
+
+``tts_batch`` is the build's utterance-batched entry (the reference is batch-1): LLM decode batched over B
+sequences, flow batched over B CFG pairs, HiFT batched over B mels.
+"""
+import threading
+import time
+import uuid
+from contextlib import nullcontext
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def fade_in_out(fade_in_mel, fade_out_mel, window):
+    """utils/common.py:149-157 (host-side cross-fade of the stream seam)."""
+    device = fade_in_mel.device
+    fade_in_mel, fade_out_mel = fade_in_mel.cpu().clone(), fade_out_mel.cpu()
+    n = int(window.shape[0] / 2)
+    fade_in_mel[..., :n] = fade_in_mel[..., :n] * window[:n] + fade_out_mel[..., -n:] * window[n:]
+    return fade_in_mel.to(device)
+
+
+class CosyVoice2Model:
+    def __init__(self, llm, flow, hift, fp16: bool = False):
+        self.device = torch.device("cuda")
+        if not torch.cuda.is_available():
+            raise RuntimeError("cosyvoice_amd needs an MI355X (no CPU fallback)")
+        self.llm, self.flow, self.hift = llm, flow, hift
+        self.fp16 = fp16
+        self.llm.fp16 = fp16
+        self.flow.fp16 = fp16
+        self.token_hop_len = 2 * self.flow.input_frame_rate
+        # model.py:313-315
+        self.flow.encoder.static_chunk_size = 2 * self.flow.input_frame_rate
+        self.flow.decoder.estimator.static_chunk_size = 2 * self.flow.input_frame_rate * self.flow.token_mel_ratio
+        self.mel_cache_len = 8
+        self.source_cache_len = int(self.mel_cache_len * 480)
+        self.speech_window = np.hamming(2 * self.source_cache_len)
+        self.stream_scale_factor = 1
+        self.llm_context = torch.cuda.stream(torch.cuda.Stream(self.device))
+        self.lock = threading.Lock()
+        self.tts_speech_token_dict = {}
+        self.llm_end_dict = {}
+        self.hift_cache_dict = {}
+
+    def load(self, llm_model, flow_model, hift_model):
+        """model.py:71-81 — three flat state-dict files with the reference key names."""
+        self.llm.load_state_dict(torch.load(llm_model, map_location="cpu", weights_only=True), strict=False)
+        self.flow.load_state_dict(torch.load(flow_model, map_location="cpu", weights_only=True), strict=False)
+        hift_sd = {k.replace("generator.", ""): v for k, v in torch.load(hift_model, map_location="cpu", weights_only=True).items()}
+        self.hift.load_state_dict(hift_sd, strict=False)
+
+    def load_state_dicts(self, llm_sd, flow_sd, hift_sd):
+        self.llm.load_state_dict(llm_sd)
+        self.flow.load_state_dict(flow_sd)
+        self.hift.load_state_dict(hift_sd)
+        return self
+
+    def llm_job(self, text, prompt_text, llm_prompt_speech_token, llm_embedding, uuid_):
+        # model.py:116-128
+        with self.llm_context:
+            for i in self.llm.inference(text=text.to(self.device),
+                                        text_len=torch.tensor([text.shape[1]], dtype=torch.int32),
+                                        prompt_text=prompt_text.to(self.device),
+                                        prompt_text_len=torch.tensor([prompt_text.shape[1]], dtype=torch.int32),
+                                        prompt_speech_token=llm_prompt_speech_token.to(self.device),
+                                        prompt_speech_token_len=torch.tensor([llm_prompt_speech_token.shape[1]], dtype=torch.int32),
+                                        embedding=llm_embedding):
+                self.tts_speech_token_dict[uuid_].append(i)
+        self.llm_end_dict[uuid_] = True
+
+    def token2wav(self, token, prompt_token, prompt_feat, embedding, uuid_, token_offset, finalize=False, speed=1.0):
+        # model.py:334-366
+        tts_mel, _ = self.flow.inference(token=token.to(self.device),
+                                         token_len=torch.tensor([token.shape[1]], dtype=torch.int32),
+                                         prompt_token=prompt_token.to(self.device),
+                                         prompt_token_len=torch.tensor([prompt_token.shape[1]], dtype=torch.int32),
+                                         prompt_feat=prompt_feat.to(self.device),
+                                         prompt_feat_len=torch.tensor([prompt_feat.shape[1]], dtype=torch.int32),
+                                         embedding=embedding.to(self.device), finalize=finalize)
+        tts_mel = tts_mel[:, :, token_offset * self.flow.token_mel_ratio:]
+        if self.hift_cache_dict[uuid_] is not None:
+            hift_cache_mel, hift_cache_source = self.hift_cache_dict[uuid_]["mel"], self.hift_cache_dict[uuid_]["source"]
+            tts_mel = torch.concat([hift_cache_mel, tts_mel], dim=2)
+        else:
+            hift_cache_source = torch.zeros(1, 1, 0)
+        if finalize is False:
+            tts_speech, tts_source = self.hift.inference(speech_feat=tts_mel, cache_source=hift_cache_source)
+            tts_speech, tts_source = tts_speech.clone(), tts_source.clone()
+            if self.hift_cache_dict[uuid_] is not None:
+                tts_speech = fade_in_out(tts_speech, self.hift_cache_dict[uuid_]["speech"], self.speech_window)
+            self.hift_cache_dict[uuid_] = {"mel": tts_mel[:, :, -self.mel_cache_len:].clone(),
+                                           "source": tts_source[:, :, -self.source_cache_len:].clone(),
+                                           "speech": tts_speech[:, -self.source_cache_len:].clone()}
+            tts_speech = tts_speech[:, :-self.source_cache_len]
+        else:
+            if speed != 1.0:
+                assert self.hift_cache_dict[uuid_] is None, "speed change only support non-stream inference mode"
+                tts_mel = F.interpolate(tts_mel, size=int(tts_mel.shape[2] / speed), mode="linear")
+            tts_speech, tts_source = self.hift.inference(speech_feat=tts_mel, cache_source=hift_cache_source)
+            tts_speech = tts_speech.clone()
+            if self.hift_cache_dict[uuid_] is not None:
+                tts_speech = fade_in_out(tts_speech, self.hift_cache_dict[uuid_]["speech"], self.speech_window)
+        return tts_speech
+
+    def tts(self, text, flow_embedding, llm_embedding=torch.zeros(0, 192), prompt_text=torch.zeros(1, 0, dtype=torch.int32),
+            llm_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32), flow_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32),
+            prompt_speech_feat=torch.zeros(1, 0, 80), stream=False, speed=1.0, **kwargs):
+        # model.py:368-424
+        this_uuid = str(uuid.uuid1())
+        with self.lock:
+            self.tts_speech_token_dict[this_uuid], self.llm_end_dict[this_uuid] = [], False
+            self.hift_cache_dict[this_uuid] = None
+        p = threading.Thread(target=self.llm_job, args=(text, prompt_text, llm_prompt_speech_token, llm_embedding, this_uuid))
+        p.start()
+        if stream is True:
+            token_offset = 0
+            need = self.token_hop_len + self.flow.pre_lookahead_len
+            while True:
+                time.sleep(0.02)
+                if len(self.tts_speech_token_dict[this_uuid]) - token_offset >= need:
+                    this_tok = torch.tensor(self.tts_speech_token_dict[this_uuid][:token_offset + need]).unsqueeze(dim=0)
+                    this_speech = self.token2wav(token=this_tok, prompt_token=flow_prompt_speech_token, prompt_feat=prompt_speech_feat,
+                                                 embedding=flow_embedding, uuid_=this_uuid, token_offset=token_offset, finalize=False)
+                    token_offset += self.token_hop_len
+                    yield {"tts_speech": this_speech.cpu()}
+                if self.llm_end_dict[this_uuid] is True and len(self.tts_speech_token_dict[this_uuid]) - token_offset < need:
+                    break
+            p.join()
+            this_tok = torch.tensor(self.tts_speech_token_dict[this_uuid]).unsqueeze(dim=0)
+            this_speech = self.token2wav(token=this_tok, prompt_token=flow_prompt_speech_token, prompt_feat=prompt_speech_feat,
+                                         embedding=flow_embedding, uuid_=this_uuid, token_offset=token_offset, finalize=True)
+            yield {"tts_speech": this_speech.cpu()}
+        else:
+            p.join()
+            this_tok = torch.tensor(self.tts_speech_token_dict[this_uuid]).unsqueeze(dim=0)
+            this_speech = self.token2wav(token=this_tok, prompt_token=flow_prompt_speech_token, prompt_feat=prompt_speech_feat,
+                                         embedding=flow_embedding, uuid_=this_uuid, token_offset=0, finalize=True, speed=speed)
+            yield {"tts_speech": this_speech.cpu()}
+        with self.lock:
+            self.tts_speech_token_dict.pop(this_uuid)
+            self.llm_end_dict.pop(this_uuid)
+            self.hift_cache_dict.pop(this_uuid)
+
+    # ------------------------------------------------------------------ utterance-batched path (beyond the reference)
+    @torch.no_grad()
+    def tts_batch(self, texts: List[torch.Tensor], prompt_texts: List[torch.Tensor], llm_prompt_speech_tokens: List[torch.Tensor],
+                  flow_prompt_speech_tokens: torch.Tensor, prompt_speech_feats: torch.Tensor, flow_embeddings: torch.Tensor,
+                  forced: Optional[List[List[int]]] = None, to_host: bool = True):
+        """B equal-shape utterances through LLM -> flow -> HiFT.  Returns wav (B,S)."""
+        toks = self.llm.generate_batch(texts, prompt_texts, llm_prompt_speech_tokens, forced=forced)
+        n = min(len(t) for t in toks)
+        assert all(len(t) == n for t in toks), "tts_batch needs equal generated lengths (use forced tokens or per-utterance tts)"
+        tok = torch.tensor(toks, dtype=torch.int32, device=self.device)
+        mel = self.flow.inference_batch(tok, flow_prompt_speech_tokens, prompt_speech_feats, flow_embeddings)
+        wav, _ = self.hift.inference(speech_feat=mel.contiguous(), cache_source=torch.zeros(1, 1, 0))
+        return wav.cpu() if to_host else wav

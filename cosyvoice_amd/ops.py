@@ -85,7 +85,7 @@ def layernorm(x, gamma, beta, eps, *, rms=False, add=None, rows_per_group=0, act
 
 
 def attention(q, k, vt, out, *, H, Hkv, Tq, Tk, scale, q_bs, ldq, k_bs, ldk, vt_ld, o_bs, ldo, B, klen=None, chunk=0,
-              causal=False, causal_off=0, bias=None, bias_bs=0, bias_hs=0, bias_ld=0):
+              causal=False, causal_off=0, bias=None, bias_bs=0, bias_hs=0, bias_ld=0, q_hs=0, k_hs=0):
     _req_cuda(q, k, vt, out, klen, bias)
     p = L.AttnParams()
     p.dtype = L.TORCH_DT[q.dtype]
@@ -96,6 +96,7 @@ def attention(q, k, vt, out, *, H, Hkv, Tq, Tk, scale, q_bs, ldq, k_bs, ldk, vt_
     p.out, p.o_bs, p.ldo = out.data_ptr(), o_bs, ldo
     p.scale, p.klen, p.chunk, p.causal, p.causal_off = scale, L.ptr(klen), chunk, int(causal), causal_off
     p.bias, p.bias_bs, p.bias_hs, p.bias_ld = L.ptr(bias), bias_bs, bias_hs, bias_ld
+    p.q_hs, p.k_hs = q_hs, k_hs
     L.check(L.lib().cv_attention(C.byref(p), L.stream_ptr()), "cv_attention")
 
 
@@ -204,3 +205,53 @@ class Graph:
                 L.lib().cv_graph_destroy(self.handle)
         except Exception:
             pass
+
+
+# ----------------------------------------------------------------------------- LLM decode helpers
+def pack_skinny(W, interleave=False):
+    """W (N,K) 16-bit device -> packed MFMA B-fragment stream (N padded to 16)."""
+    _req_cuda(W)
+    N, K = W.shape
+    ntiles = (N + 15) // 16
+    Wp = torch.empty(ntiles * (K // 32) * 64 * 8, device=W.device, dtype=W.dtype)
+    L.check(L.lib().cv_pack_skinny(C.c_void_p(W.data_ptr()), C.c_void_p(Wp.data_ptr()), N, K, int(interleave), L.stream_ptr()),
+            "cv_pack_skinny")
+    return Wp
+
+
+def skinny_gemm(A, Wp, M, N, K, *, bias=None, ksplit=1, mode=0, out_f32=None, ldo=0, slab_stride=0, out_act=None, ldoa=0):
+    _req_cuda(A, Wp, bias, out_f32, out_act)
+    p = L.SkinnyParams()
+    p.dtype, p.M, p.N, p.K = L.TORCH_DT[A.dtype], M, N, K
+    p.A, p.lda, p.Wp, p.bias = A.data_ptr(), A.stride(0), Wp.data_ptr(), L.ptr(bias)
+    p.ksplit, p.mode = ksplit, mode
+    p.out_f32, p.ldo, p.slab_stride = L.ptr(out_f32), ldo, slab_stride
+    p.out_act, p.ldoa = L.ptr(out_act), ldoa
+    L.check(L.lib().cv_skinny_gemm(C.byref(p), L.stream_ptr()), "cv_skinny_gemm")
+
+
+def rmsnorm_reduce(x, gamma, eps, xn, rows, *, slabs=None, nslab=0, slab_stride=0, ld_slab=0):
+    _req_cuda(x, gamma, xn, slabs)
+    L.check(L.lib().cv_rmsnorm_reduce(C.c_void_p(x.data_ptr()), x.stride(0), C.c_void_p(L.ptr(slabs)), nslab, C.c_int64(slab_stride), ld_slab,
+                                      C.c_void_p(gamma.data_ptr()), C.c_float(eps), C.c_void_p(xn.data_ptr()), xn.stride(0),
+                                      L.TORCH_DT[xn.dtype], rows, x.shape[1], L.stream_ptr()), "cv_rmsnorm_reduce")
+
+
+def rope_append(qkv, pos_base, rows, rows_per_seq, Hq, Hkv, inv_freq, q_out, kcache, vtcache, ctx_max):
+    _req_cuda(qkv, pos_base, inv_freq, q_out, kcache, vtcache)
+    L.check(L.lib().cv_rope_append(C.c_void_p(qkv.data_ptr()), qkv.stride(0), C.c_void_p(pos_base.data_ptr()), rows, rows_per_seq,
+                                   Hq, Hkv, C.c_void_p(inv_freq.data_ptr()), C.c_void_p(q_out.data_ptr()), q_out.stride(0),
+                                   C.c_void_p(kcache.data_ptr()), C.c_void_p(vtcache.data_ptr()), ctx_max, L.TORCH_DT[q_out.dtype],
+                                   L.stream_ptr()), "cv_rope_append")
+
+
+def decode_attention(q, kcache, vtcache, ctx_len, ctx_add, out, B, Hq, Hkv, ctx_max, scale):
+    _req_cuda(q, kcache, vtcache, ctx_len, out)
+    L.check(L.lib().cv_decode_attention(C.c_void_p(q.data_ptr()), q.stride(0), C.c_void_p(kcache.data_ptr()),
+                                        C.c_void_p(vtcache.data_ptr()), C.c_void_p(ctx_len.data_ptr()), ctx_add,
+                                        C.c_void_p(out.data_ptr()), out.stride(0), B, Hq, Hkv, ctx_max, C.c_float(scale),
+                                        L.TORCH_DT[q.dtype], L.stream_ptr()), "cv_decode_attention")
+
+
+def sample_ras(params):
+    L.check(L.lib().cv_sample_ras(C.byref(params), L.stream_ptr()), "cv_sample_ras")

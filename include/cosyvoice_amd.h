@@ -104,6 +104,7 @@ typedef struct cv_attn_params {
   int32_t chunk;            /* 0 = off */
   int32_t causal; int32_t causal_off;
   const float* bias; int64_t bias_bs, bias_hs; int32_t bias_ld; /* fp32 additive bias view or null */
+  int64_t q_hs, k_hs;       /* element stride between heads of Q / K (0 -> 64: heads packed inside a row) */
 } cv_attn_params;
 int cv_attention(const cv_attn_params* p, void* stream);
 
@@ -140,7 +141,7 @@ int cv_hift_source(const float* f0, const float* phase_vec, const float* noise, 
 /* ------------------------------------------------------------------------------------------
  * Flow-matching helpers (flow/flow.py:286-317, flow/flow_matching.py:72-124).
  * ------------------------------------------------------------------------------------------ */
-/* out[r][0:dim] = table[idx[r]][0:dim] (rows with idx < 0 -> zeros); out dtype `dtype`, ld ldo */
+/* out[r][0:dim] = table[idx[r]][0:dim]; idx == -1 -> zero row; idx == -2 -> row left untouched; out dtype `dtype`, ld ldo */
 int cv_embedding(const float* table, const int32_t* idx, void* out, int32_t dtype, int32_t rows, int32_t dim, int32_t ldo, void* stream);
 /* Estimator input for classifier-free guidance, channels-last: for utterance b, row pair (2b, 2b+1):
  *   xin[2b]   = [x | mu | spks (broadcast over T) | cond]   xin[2b+1] = [x | 0 | 0 | 0]      (flow_matching.py:95-108,

@@ -1,0 +1,72 @@
+"""GPU: the CosyVoice2Model-compatible orchestrator (tts / token2wav / llm_job / tts_batch) on tiny stage models."""
+import pytest
+import torch
+
+from cosyvoice_amd.config import FlowConfig, HiftConfig, LlmConfig
+from cosyvoice_amd.weights import flow_state_dict, hift_state_dict, llm_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _model():
+    from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
+    from cosyvoice_amd.hift import HiFTGenerator
+    from cosyvoice_amd.llm import Qwen2LM
+    from cosyvoice_amd.model import CosyVoice2Model
+    lc, fc, hc = LlmConfig.tiny(), FlowConfig.tiny(), HiftConfig.tiny()
+    llm = Qwen2LM(lc, dtype=torch.bfloat16, max_batch=4, ctx_max=256, max_out=256)
+    flow = CausalMaskedDiffWithXvec(fc, dtype=torch.float16)
+    hift = HiFTGenerator(hc, dtype=torch.float32)
+    m = CosyVoice2Model(llm, flow, hift, fp16=False).load_state_dicts(llm_state_dict(lc), flow_state_dict(fc), hift_state_dict(hc))
+    return m, lc, fc, hc
+
+
+def _inputs(lc, fc, seed=0, n_text=6, n_p=10):
+    g = torch.Generator().manual_seed(seed)
+    return dict(text=torch.randint(0, lc.vocab_size, (1, n_text), generator=g, dtype=torch.int32),
+                prompt_text=torch.randint(0, lc.vocab_size, (1, 4), generator=g, dtype=torch.int32),
+                llm_prompt_speech_token=torch.randint(0, lc.speech_token_size, (1, n_p), generator=g, dtype=torch.int32),
+                flow_prompt_speech_token=torch.randint(0, lc.speech_token_size, (1, n_p), generator=g, dtype=torch.int32),
+                prompt_speech_feat=torch.clamp(torch.randn(1, 2 * n_p, 80, generator=g) * 2 - 6, -11.5, 2.0),
+                flow_embedding=torch.randn(1, fc.spk_embed_dim, generator=g))
+
+
+def test_tts_non_stream_and_stream():
+    m, lc, fc, hc = _model()
+    inp = _inputs(lc, fc)
+    outs = list(m.tts(**inp, stream=False))
+    assert len(outs) == 1
+    wav = outs[0]["tts_speech"]
+    assert wav.device.type == "cpu" and wav.dim() == 2 and wav.shape[0] == 1
+    assert wav.shape[1] % (2 * hc.total_upsample) == 0 and wav.shape[1] > 0   # 2 mel frames per token
+    assert torch.isfinite(wav).all() and wav.abs().max().item() <= hc.audio_limit + 1e-6
+    n_tok = wav.shape[1] // (2 * hc.total_upsample)
+    assert 2 * 6 <= n_tok <= 20 * 6  # min/max token-text ratios (llm.py:855-856)
+    assert not m.tts_speech_token_dict and not m.llm_end_dict and not m.hift_cache_dict  # per-request state cleaned up
+    # streaming: chunks of token_hop_len (model.py:380-407); the tiny HiFT hop differs from 480 so only shapes are checked
+    m.source_cache_len = m.mel_cache_len * hc.total_upsample
+    import numpy as np
+    m.speech_window = np.hamming(2 * m.source_cache_len)
+    chunks = [o["tts_speech"] for o in m.tts(**inp, stream=True)]
+    assert len(chunks) >= 1 and all(torch.isfinite(c).all() for c in chunks)
+
+
+def test_tts_batch_matches_single_with_forced_tokens():
+    m, lc, fc, hc = _model()
+    B = 3
+    ins = [_inputs(lc, fc, seed=s) for s in range(B)]
+    g = torch.Generator().manual_seed(9)
+    forced = [torch.randint(0, lc.speech_token_size, (14,), generator=g).tolist() for _ in range(B)]
+    shared = ins[0]
+    torch.manual_seed(0)
+    wav = m.tts_batch([i["text"] for i in ins], [shared["prompt_text"]] * B, [shared["llm_prompt_speech_token"]] * B,
+                      shared["flow_prompt_speech_token"].expand(B, -1), shared["prompt_speech_feat"].expand(B, -1, -1),
+                      shared["flow_embedding"].expand(B, -1), forced=forced)
+    assert wav.shape == (B, 14 * 2 * hc.total_upsample) and torch.isfinite(wav).all()
+    # the deterministic part (flow mel) of each utterance equals its batch-1 run
+    tok = torch.tensor(forced, dtype=torch.int32)
+    mel_b = m.flow.inference_batch(tok, shared["flow_prompt_speech_token"].expand(B, -1), shared["prompt_speech_feat"].expand(B, -1, -1),
+                                   shared["flow_embedding"].expand(B, -1)).clone()
+    for b in range(B):
+        mel_1 = m.flow.inference_batch(tok[b:b + 1], shared["flow_prompt_speech_token"], shared["prompt_speech_feat"], shared["flow_embedding"])
+        assert (mel_1[0] - mel_b[b]).abs().max().item() < 1e-4
