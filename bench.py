@@ -117,7 +117,7 @@ def main():
     lsd, fsd, hsd = llm_state_dict(lc), flow_state_dict(fc), hift_state_dict(hc)
     log(f"[rank {rank}] synthetic weights generated in {time.time()-t0:.1f}s")
     fdt = torch.float16 if args.flow_dtype == "fp16" else torch.bfloat16
-    llm = Qwen2LM(lc, dtype=torch.bfloat16, max_batch=UTT_PER_GPU, ctx_max=576, max_out=N_GEN + 8)
+    llm = Qwen2LM(lc, dtype=torch.bfloat16, max_batch=UTT_PER_GPU, ctx_max=704, max_out=N_GEN + 8)
     flow = CausalMaskedDiffWithXvec(fc, dtype=fdt)
     hift = HiFTGenerator(hc, dtype=torch.float32)
     model = CosyVoice2Model(llm, flow, hift, fp16=False).load_state_dicts(lsd, fsd, hsd)
