@@ -72,6 +72,10 @@ class SkinnyParams(C.Structure):
         ("ksplit", _i32), ("mode", _i32),
         ("out_f32", _vp), ("ldo", _i32), ("slab_stride", _i64),
         ("out_act", _vp), ("ldoa", _i32),
+        ("nx", _vp), ("ldnx", _i32),
+        ("nslabs", _vp), ("n_nslab", _i32), ("nslab_stride", _i64), ("ld_nslab", _i32),
+        ("ngamma", _vp), ("neps", _f32),
+        ("nx_out", _vp),
     ]
 
 

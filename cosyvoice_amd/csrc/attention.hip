@@ -40,46 +40,35 @@ __global__ __launch_bounds__(256) void attn_kernel(const cv_attn_params p) {
   if (p.chunk > 0) limit = min(limit, (q_max / p.chunk + 1) * p.chunk);
   const int ntiles = (limit + 63) >> 6;
 
-  // ---- Q fragments (B operand of S^T): lane = query (lq), d chunk = ks*4 + lg
+  // ---- Q fragments (B operand of S^T): lane = query (lq), d chunk = ks*4 + lg.  Loads are unconditional (clamped
+  // rows, masked afterwards): a load under a per-element branch costs a vmcnt(0) wait each.
   uint4 qf[2][2];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     const int row = q0 + qt * 16 + lq;
+    const uint32_t msk = row < p.Tq ? 0xFFFFFFFFu : 0u;
+    const int rc = min(row, p.Tq - 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      qf[qt][ks] = make_uint4(0, 0, 0, 0);
-      if (row < p.Tq) qf[qt][ks] = *(const uint4*)(Q + (int64_t)row * p.ldq + (ks * 4 + lg) * 8);
+      const uint4 v = *(const uint4*)(Q + (int64_t)rc * p.ldq + (ks * 4 + lg) * 8);
+      qf[qt][ks] = make_uint4(v.x & msk, v.y & msk, v.z & msk, v.w & msk);
     }
   }
 
   uint4 rk[2], rv[2];
+  int tile_j0 = 0;  // key offset of the prefetched tile: validity masks are applied when it is written to LDS, so the
+                    // loads stay in flight across the MFMA block (masking at load time would force the wait up here)
+  const int key_max = max(klen - 1, 0);
+  const int vchunk_max = max(((klen + 7) & ~7) - 8, 0);  // last 8-key chunk that holds a valid key (vt_ld % 8 == 0)
   auto load_tile = [&](int t) {
     const int j0 = t << 6;
+    tile_j0 = j0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = i * 256 + tid;
       const int r = c >> 3, dc = c & 7;
-      // K: r = key within tile, dc = d chunk
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (j0 + r < klen) v = *(const uint4*)(Kp + (int64_t)(j0 + r) * p.ldk + dc * 8);
-      rk[i] = v;
-      // V^T: r = d row, dc = key chunk (8 keys); zero every key >= klen (0 * garbage must not become NaN)
-      const int kbase = j0 + dc * 8;
-      uint4 w = make_uint4(0, 0, 0, 0);
-      if (kbase < klen) {
-        w = *(const uint4*)(Vt + (int64_t)r * p.vt_ld + kbase);
-        const int nvalid = klen - kbase;  // >= 1
-        if (nvalid < 8) {
-          uint32_t* u = (uint32_t*)&w;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int k0 = 2 * e;
-            if (k0 >= nvalid) u[e] = 0;
-            else if (k0 + 1 >= nvalid) u[e] &= 0xFFFFu;
-          }
-        }
-      }
-      rv[i] = w;
+      rk[i] = *(const uint4*)(Kp + (int64_t)min(j0 + r, key_max) * p.ldk + dc * 8);      // r = key, dc = d chunk
+      rv[i] = *(const uint4*)(Vt + (int64_t)r * p.vt_ld + min(j0 + dc * 8, vchunk_max));  // r = d row, dc = key chunk
     }
   };
   auto store_tile = [&](int s) {
@@ -89,8 +78,19 @@ __global__ __launch_bounds__(256) void attn_kernel(const cv_attn_params p) {
     for (int i = 0; i < 2; ++i) {
       const int c = i * 256 + tid;
       const int r = c >> 3, dc = c & 7;
-      *(uint4*)(sk + (((r >> 4) * 2 + (dc >> 2)) << 10) + ((dc & 3) << 8) + ((r & 15) << 4)) = rk[i];
-      *(uint4*)(sv + r * VT_PITCH + dc * 16) = rv[i];
+      const uint32_t km = (tile_j0 + r < klen) ? 0xFFFFFFFFu : 0u;
+      *(uint4*)(sk + (((r >> 4) * 2 + (dc >> 2)) << 10) + ((dc & 3) << 8) + ((r & 15) << 4)) =
+          make_uint4(rk[i].x & km, rk[i].y & km, rk[i].z & km, rk[i].w & km);
+      // zero every key >= klen of the V^T chunk (0 * garbage must not become NaN)
+      const int nvalid = klen - (tile_j0 + dc * 8);
+      uint32_t u[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t m_lo = (2 * e < nvalid) ? 0x0000FFFFu : 0u;
+        const uint32_t m_hi = (2 * e + 1 < nvalid) ? 0xFFFF0000u : 0u;
+        u[e] &= (m_lo | m_hi);
+      }
+      *(uint4*)(sv + r * VT_PITCH + dc * 16) = make_uint4(u[0], u[1], u[2], u[3]);
     }
   };
 
@@ -138,8 +138,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const cv_attn_params p) {
       int jlim = klen;
       if (p.causal) jlim = min(jlim, i + p.causal_off + 1);
       if (p.chunk > 0) jlim = min(jlim, (i / p.chunk + 1) * p.chunk);
-      const float* brow = nullptr;
-      if (p.bias && i < p.Tq) brow = p.bias + (int64_t)b * p.bias_bs + (int64_t)h * p.bias_hs + (int64_t)i * p.bias_ld;
+      const bool has_bias = p.bias != nullptr;
+      const float* brow = has_bias ? p.bias + (int64_t)b * p.bias_bs + (int64_t)h * p.bias_hs + (int64_t)min(i, p.Tq - 1) * p.bias_ld : nullptr;
       float mx = NEG_BIG;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const cv_attn_params p) {
         for (int r = 0; r < 4; ++r) {
           const int j = j0 + kt * 16 + 4 * lg + r;
           float v = sacc[kt][qt][r] * sc;
-          if (brow && j < jlim) v += brow[j] * 1.4426950408889634f;
+          if (has_bias) v += brow[min(j, p.Tk - 1)] * 1.4426950408889634f;  // wave-uniform branch, clamped address
           v = (j < jlim) ? v : NEG_BIG;
           sacc[kt][qt][r] = v;
           mx = fmaxf(mx, v);

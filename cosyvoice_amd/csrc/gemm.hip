@@ -6,8 +6,10 @@
 // per row = one full 128-byte line) -> LDS -> ds_read_b128 fragments -> MFMA.
 // LDS image: each (16 rows x 4 chunks) block is stored [chunk][row][16 B], so lane l of a wave reads bytes
 // [16 l, 16 l + 16) of the block: linear, conflict-free for ds_read_b128 (MI355X_MICROARCH.md §LDS).
-// Double-buffered LDS + register prefetch: one barrier per K tile, the next tile's global loads fly during the MFMAs.
+// One LDS stage + register prefetch: the next tile's global loads fly during the MFMAs; 32 KiB of LDS per 128x128
+// workgroup keeps 4 workgroups resident per CU.
 #include "cv_device.h"
+#include <cstdlib>
 
 namespace {
 
@@ -66,22 +68,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(const cv_gemm_params p) {
   const bool conv = p.cin != p.K;
 
   uint4 ra[A_CH], rb[B_CH];
+  uint32_t amask = 0, bmask = 0;  // validity bits of the prefetched chunks; applied when the tile is written to LDS
 
+  // Tile loads are UNCONDITIONAL (addresses clamped into the operand, out-of-range chunks masked to zero afterwards):
+  // `if (ok) v = load` makes hipcc branch around every load and wait vmcnt(0) each time, which serialises the K loop
+  // on memory latency (cdna_hip_programming.md §5 "Three .s-level traps" (c)).
+  const int a_row_max = p.a_rows - 1, n_max = p.N - 1, k_max = p.K - CH;
   auto load_tile = [&](int kt) {
     const int kbase = kt * BK;
+    amask = 0;
+    bmask = 0;
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       const int c = i * 256 + tid;
       const int row = c >> 3, kc = c & 7;
       const int m = m0 + row;
       const int k = kbase + kc * CH;
-      int tap = 0, ci = k;
-      if (conv) { tap = k / p.cin; ci = k - tap * p.cin; }
+      const int kcl = min(k, k_max);
+      int tap = 0, ci = kcl;
+      if (conv) { tap = kcl / p.cin; ci = kcl - tap * p.cin; }
       const int arow = m * p.a_row_stride + p.tap_base + tap * p.tap_step;
-      const bool ok = (m < p.M) && (k < p.K) && (arow >= 0) && (arow < p.a_rows);
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) v = *(const uint4*)(Ab + ((int64_t)arow * p.lda + ci) * ES);
-      ra[i] = v;
+      const bool ok = (m < p.M) && (k < p.K) && (arow >= 0) && (arow <= a_row_max);
+      const int arc = min(max(arow, 0), a_row_max);
+      ra[i] = *(const uint4*)(Ab + ((int64_t)arc * p.lda + ci) * ES);
+      amask |= (ok ? 1u : 0u) << i;
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
@@ -89,9 +99,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const cv_gemm_params p) {
       const int row = c >> 3, kc = c & 7;
       const int n = n0 + row;
       const int k = kbase + kc * CH;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (n < p.N && k < p.K) v = *(const uint4*)(Wb + ((int64_t)n * p.ldw + k) * ES);
-      rb[i] = v;
+      const bool ok = (n < p.N) && (k < p.K);
+      rb[i] = *(const uint4*)(Wb + ((int64_t)min(n, n_max) * p.ldw + min(k, k_max)) * ES);
+      bmask |= (ok ? 1u : 0u) << i;
     }
   };
   auto store_tile = [&](int s) {
@@ -100,12 +110,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const cv_gemm_params p) {
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       const int c = i * 256 + tid;
-      *(uint4*)(sa + lds_chunk_off(c >> 3, c & 7)) = ra[i];
+      const uint32_t mk = ((amask >> i) & 1u) ? 0xFFFFFFFFu : 0u;
+      *(uint4*)(sa + lds_chunk_off(c >> 3, c & 7)) = make_uint4(ra[i].x & mk, ra[i].y & mk, ra[i].z & mk, ra[i].w & mk);
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
       const int c = i * 256 + tid;
-      *(uint4*)(sb + lds_chunk_off(c >> 3, c & 7)) = rb[i];
+      const uint32_t mk = ((bmask >> i) & 1u) ? 0xFFFFFFFFu : 0u;
+      *(uint4*)(sb + lds_chunk_off(c >> 3, c & 7)) = make_uint4(rb[i].x & mk, rb[i].y & mk, rb[i].z & mk, rb[i].w & mk);
     }
   };
 
@@ -115,14 +127,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const cv_gemm_params p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  // single LDS stage (32 KiB at 128x128 -> 4 workgroups per CU) + register prefetch of the next K tile:
+  // occupancy, not a second LDS buffer, hides the global-load latency of these short-K GEMMs
   load_tile(0);
   store_tile(0);
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
-    const int s = kt & 1;
     if (kt + 1 < nk) load_tile(kt + 1);
-    const char* sa = smem + s * STAGE;
+    const char* sa = smem;
     const char* sb = sa + BM * 128;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -136,18 +149,80 @@ __global__ __launch_bounds__(256) void gemm_kernel(const cv_gemm_params p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = mfma_block<DT>(fb[j], fa[i], acc[i][j]);
     }
-    if (kt + 1 < nk) store_tile(s ^ 1);
-    __syncthreads();
+    if (kt + 1 < nk) {
+      __syncthreads();
+      store_tile(0);
+      __syncthreads();
+    }
   }
 
   // ------------------------------------------------------------------ epilogue
   // acc[i][j][r]: m = m0 + (wave_m*MT + i)*16 + (lane&15);  n = n0 + (wave_n*NT + j)*16 + 4*(lane>>4) + r
+  // All bias / residual / act-param loads are issued UNCONDITIONALLY (clamped addresses, results masked) and hoisted in
+  // front of the arithmetic: a load inside a per-element branch makes hipcc wait vmcnt(0) per element
+  // (cdna_hip_programming.md §5 "Three .s-level traps" (c)) — that serialisation dominated the first version.
   const int lm = lane & 15, lg = lane >> 4;
   const int64_t res_off = z0 * p.res_bs0 + z1 * p.res_bs1;
   float* o32 = p.out_f32 ? p.out_f32 + (z0 * p.o32_bs0 + z1 * p.o32_bs1) : nullptr;
   char* oact = p.out_act ? (char*)p.out_act + (z0 * p.oa_bs0 + z1 * p.oa_bs1) * ES : nullptr;
-  const bool vec = ((p.N & 3) == 0) && (p.act != CV_ACT_SWIGLU);
+  const bool vec = ((p.N & 3) == 0) && (p.act != CV_ACT_SWIGLU) && (p.out_mode == CV_OUT_ROWMAJOR);
 
+  if (vec) {
+    const bool has_res = p.res != nullptr, has_res2 = p.res2 != nullptr;
+    float4 b4[NT], ap4[NT];
+    int nbj[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int nb = n0 + (wave_n * NT + j) * 16 + 4 * lg;
+      nbj[j] = nb;
+      const int nc = nb < p.N ? nb : 0;  // N % 4 == 0: a 4-group is entirely in or out
+      b4[j] = p.bias ? *(const float4*)(p.bias + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      ap4[j] = p.act_param ? *(const float4*)(p.act_param + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    int orow[MT];
+    bool rok[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + (wave_m * MT + i) * 16 + lm;
+      const int r_ = m * p.out_row_stride + p.out_row_off;
+      rok[i] = (m < p.M) && (r_ >= 0) && (r_ < p.out_rows);
+      orow[i] = rok[i] ? r_ : (p.out_row_off >= 0 && p.out_row_off < p.out_rows ? p.out_row_off : 0);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float4 r4[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int nc = nbj[j] < p.N ? nbj[j] : 0;
+        r4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_res) r4[j] = *(const float4*)(p.res + res_off + (int64_t)orow[i] * p.ldres + nc);
+      }
+      if (has_res2) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int nc = nbj[j] < p.N ? nbj[j] : 0;
+          const float4 q = *(const float4*)(p.res2 + res_off + (int64_t)orow[i] * p.ldres2 + nc);
+          r4[j].x += q.x; r4[j].y += q.y; r4[j].z += q.z; r4[j].w += q.w;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (!rok[i] || nbj[j] >= p.N) continue;
+        const float v0 = (acc[i][j][0] + b4[j].x + r4[j].x) * p.out_scale;
+        const float v1 = (acc[i][j][1] + b4[j].y + r4[j].y) * p.out_scale;
+        const float v2 = (acc[i][j][2] + b4[j].z + r4[j].z) * p.out_scale;
+        const float v3 = (acc[i][j][3] + b4[j].w + r4[j].w) * p.out_scale;
+        if (o32) *(float4*)(o32 + (int64_t)orow[i] * p.ldo32 + nbj[j]) = make_float4(v0, v1, v2, v3);
+        if (oact)
+          store_act4<DT>(oact, (int64_t)orow[i] * p.ldoa + nbj[j], apply_act(p.act, v0, ap4[j].x, p.act_slope),
+                         apply_act(p.act, v1, ap4[j].y, p.act_slope), apply_act(p.act, v2, ap4[j].z, p.act_slope),
+                         apply_act(p.act, v3, ap4[j].w, p.act_slope));
+      }
+    }
+    return;
+  }
+
+  // ---- general path (N % 4 != 0, SwiGLU pairs, QKV split): correctness first, used by a handful of small launches
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = m0 + (wave_m * MT + i) * 16 + lm;
@@ -201,20 +276,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const cv_gemm_params p) {
         }
         continue;
       }
-      if (vec) {
-        if (o32) *(float4*)(o32 + (int64_t)orow * p.ldo32 + nb) = make_float4(v[0], v[1], v[2], v[3]);
-        if (oact) {
-          store_act4<DT>(oact, (int64_t)orow * p.ldoa + nb, apply_act(p.act, v[0], ap[0], p.act_slope),
-                         apply_act(p.act, v[1], ap[1], p.act_slope), apply_act(p.act, v[2], ap[2], p.act_slope),
-                         apply_act(p.act, v[3], ap[3], p.act_slope));
-        }
-      } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (nb + r >= p.N) continue;
-          if (o32) o32[(int64_t)orow * p.ldo32 + nb + r] = v[r];
-          if (oact) store_act<DT>(oact, (int64_t)orow * p.ldoa + nb + r, apply_act(p.act, v[r], ap[r], p.act_slope));
-        }
+      for (int r = 0; r < 4; ++r) {
+        if (nb + r >= p.N) continue;
+        if (o32) o32[(int64_t)orow * p.ldo32 + nb + r] = v[r];
+        if (oact) store_act<DT>(oact, (int64_t)orow * p.ldoa + nb + r, apply_act(p.act, v[r], ap[r], p.act_slope));
       }
     }
   }
@@ -224,19 +290,35 @@ template <int DT, int BM, int BN>
 int launch(const cv_gemm_params& p, hipStream_t st) {
   const int mt = (p.M + BM - 1) / BM, nt = (p.N + BN - 1) / BN;
   dim3 grid(mt * nt, 1, p.batch);
-  const size_t lds = 2 * (BM + BN) * 128;
+  const size_t lds = (BM + BN) * 128;
   hipLaunchKernelGGL((gemm_kernel<DT, BM, BN>), grid, dim3(256), lds, st, p);
   CV_CHECK_LAUNCH();
   return CV_OK;
 }
 
+// CV_GEMM_TILE=0|1|2 (128x128 | 128x64 | 64x64) overrides the heuristic: tuning aid only
+static int g_tile_override = -2;
+
 template <int DT>
 int dispatch(const cv_gemm_params& p, hipStream_t st) {
-  // tile choice: fill >= ~1 wave of the 256 CUs; small problems take the 64x64 tile
-  const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch;
-  if (t128 >= 192 && p.N >= 96 && p.act != CV_ACT_SWIGLU) return launch<DT, 128, 128>(p, st);
-  const long long t12864 = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * p.batch;
-  if (t12864 >= 192) return launch<DT, 128, 64>(p, st);
+  if (g_tile_override == -2) {
+    const char* e = getenv("CV_GEMM_TILE");
+    g_tile_override = e ? atoi(e) : -1;
+  }
+  const bool swiglu = p.act == CV_ACT_SWIGLU;
+  int tile = g_tile_override;
+  if (tile < 0) {
+    // These GEMMs have short K (256..1024): latency is hidden by resident workgroups, not by pipeline depth, so prefer
+    // the largest tile that still puts >= ~4 workgroups on every CU.
+    // measured on MI355X (tools/gemm_bench.py, profiles/r01_gemm_tile_sweep.txt): 64x64 wins for K <= 512 and whenever
+    // 128x64 would leave < ~3 workgroups per CU; 128x64 wins for long K with many tiles; 128x128 never wins here.
+    const long long t12864 = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * p.batch;
+    if (p.K > 512 && t12864 >= 768) tile = 1;
+    else tile = 2;
+  }
+  if (swiglu && tile == 0) tile = 1;
+  if (tile == 0) return launch<DT, 128, 128>(p, st);
+  if (tile == 1) return launch<DT, 128, 64>(p, st);
   return launch<DT, 64, 64>(p, st);
 }
 

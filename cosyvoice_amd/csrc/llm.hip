@@ -32,9 +32,17 @@ __global__ __launch_bounds__(256) void pack_skinny_kernel(const uint16_t* W, uin
 }
 
 // =========================================================================================== skinny GEMM
-template <int DT, int TPW>
+// One workgroup = TPW 16-column tiles x a K slice; the 4 waves split the slice, every wave streams its packed weight
+// fragments (1 KiB per wave-load, non-temporal) straight into MFMA B operands and reduces through LDS at the end.
+// NORM: the activation operand is produced in the prologue (residual + split-K slabs -> RMSNorm -> 16-bit, staged in
+// LDS in fragment order); the weight loads of the first chunk are issued BEFORE the prologue so HBM latency hides under it.
+// NORM: 0 = A from global memory, 1 = fused RMSNorm prologue, 2 = prologue + split-K slab reduction.
+// TPR = threads per activation row in the prologue (256/TPR rows): 64 for M <= 4, 32 for M <= 8, 16 otherwise.
+template <int DT, int TPW, int NORM, int TPR>
 __global__ __launch_bounds__(256) void skinny_kernel(const cv_skinny_params p) {
-  __shared__ float red[4][TPW][64][4];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float (*red)[TPW][64][4] = (float (*)[TPW][64][4])smem;           // [4][TPW][64][4]
+  char* aimg = smem + 4 * TPW * 64 * 4 * sizeof(float);             // NORM: [nks][64 lanes][16 B]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int nks = p.K >> 5;
   const int per = (nks + p.ksplit - 1) / p.ksplit;
@@ -43,25 +51,110 @@ __global__ __launch_bounds__(256) void skinny_kernel(const cv_skinny_params p) {
   const int w0 = kb + wid * pw, w1 = min(ke, w0 + pw);
   const int tile0 = blockIdx.x * TPW;
 
-  const uint16_t* Arow = (const uint16_t*)p.A + (int64_t)(lane & 15) * p.lda + 8 * (lane >> 4);
   const uint4* Wt[TPW];
 #pragma unroll
   for (int t = 0; t < TPW; ++t) Wt[t] = (const uint4*)p.Wp + (int64_t)(tile0 + t) * nks * 64 + lane;
 
+  constexpr int U = 8;
+  uint4 w[TPW][U];
+  auto load_w = [&](int ks) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        // unconditional (clamped) load: a branch per element would serialise the stream with vmcnt(0) waits
+        const int kk = (ks + u < w1) ? ks + u : max(w1 - 1, 0);
+        w[t][u] = nt_load16(Wt[t] + (int64_t)kk * 64);
+      }
+  };
+
+  if constexpr (NORM != 0) {
+    // TPR threads per row; thread handles float4 columns c = sub + TPR i.  Every load is unconditional (rows >= M and
+    // columns beyond K are clamped and masked arithmetically) so the whole prologue is one batch of loads + one wait.
+    constexpr int NV = 256 / TPR;  // float4 per thread for K <= 1024
+    const int row = tid / TPR, sub = tid % TPR;
+    const int nq = p.K >> 2;  // float4 per row
+    const bool live = row < p.M;
+    const int rowc = live ? row : 0;
+    const float* xr = p.nx + (int64_t)rowc * p.ldnx;
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = *(const float4*)(xr + min(sub + TPR * i, nq - 1) * 4);
+    if constexpr (NORM == 2) {
+      const float* sl = p.nslabs + (int64_t)rowc * p.ld_nslab;
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        // slab index clamped, contribution weighted 0/1: no branch around the loads
+        const float wgt = s2 < p.n_nslab ? 1.f : 0.f;
+        const float* sp = sl + (int64_t)min(s2, p.n_nslab - 1) * p.nslab_stride;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const float4 q = *(const float4*)(sp + min(sub + TPR * i, nq - 1) * 4);
+          v[i].x += wgt * q.x; v[i].y += wgt * q.y; v[i].z += wgt * q.z; v[i].w += wgt * q.w;
+        }
+      }
+    }
+    float4 gm[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) gm[i] = *(const float4*)(p.ngamma + min(sub + TPR * i, nq - 1) * 4);
+    load_w(w0);  // weight stream issued behind the (L2-resident) activation loads; it lands during the norm arithmetic
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float msk = (sub + TPR * i < nq && live) ? 1.f : 0.f;
+      ss += msk * (v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+#pragma unroll
+    for (int o = TPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float rstd = rsqrtf(ss / (float)p.K + p.neps);
+    const bool writer = p.nx_out && blockIdx.x == 0 && blockIdx.y == 0 && live;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = sub + TPR * i;
+      if (c >= nq) continue;
+      uint2 u = make_uint2(0, 0);
+      if (live) {
+        u.x = pack2<DT>(v[i].x * rstd * gm[i].x, v[i].y * rstd * gm[i].y);
+        u.y = pack2<DT>(v[i].z * rstd * gm[i].z, v[i].w * rstd * gm[i].w);
+      }
+      if (writer) *(float4*)(p.nx_out + (int64_t)row * p.ldnx + c * 4) = v[i];
+      // element k0 = 4c: chunk kc = c >> 1 (8 elements), half = c & 1; fragment slot (ks = kc >> 2, g = kc & 3, row)
+      const int kc = c >> 1;
+      *(uint2*)(aimg + ((((kc >> 2) * 64) + (kc & 3) * 16 + row) << 4) + (c & 1) * 8) = u;
+    }
+    if constexpr (TPR > 16) {
+      // rows 256/TPR .. 15 of the fragment image are never written by the loop above: zero them (they feed MFMA lanes
+      // whose results are discarded, but must be finite)
+      constexpr int ROWS = 256 / TPR;
+      const int nks_ = p.K >> 5;
+      for (int idx = tid; idx < nks_ * 4 * (16 - ROWS); idx += 256) {
+        const int r_ = ROWS + idx % (16 - ROWS), kg = idx / (16 - ROWS);  // kg = ks*4 + g
+        *(uint4*)(aimg + (((kg >> 2) * 64 + (kg & 3) * 16 + r_) << 4)) = make_uint4(0, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  } else {
+    load_w(w0);
+  }
+
+  const uint16_t* Arow = (NORM != 0) ? nullptr : (const uint16_t*)p.A + (int64_t)(lane & 15) * p.lda + 8 * (lane >> 4);
   f32x4_t acc[TPW];
 #pragma unroll
   for (int t = 0; t < TPW; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  constexpr int U = 8;
   for (int ks = w0; ks < w1; ks += U) {
-    uint4 a[U], w[TPW][U];
+    if (ks != w0) load_w(ks);
+    uint4 a[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      // unconditional clamped load, masked to zero beyond the slice (the clamped weight fragment then contributes 0)
       const bool ok = ks + u < w1;
-      a[u] = ok ? *(const uint4*)(Arow + (ks + u) * 32) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < TPW; ++t)
-        w[t][u] = ok ? nt_load16(Wt[t] + (int64_t)(ks + u) * 64) : make_uint4(0, 0, 0, 0);
+      const int kk = ok ? ks + u : max(w1 - 1, 0);
+      uint4 t;
+      if constexpr (NORM != 0) t = *(const uint4*)(aimg + ((kk * 64 + lane) << 4));
+      else t = *(const uint4*)(Arow + kk * 32);
+      const uint32_t msk = ok ? 0xFFFFFFFFu : 0u;
+      a[u] = make_uint4(t.x & msk, t.y & msk, t.z & msk, t.w & msk);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -129,13 +222,13 @@ __global__ __launch_bounds__(256) void rmsnorm_reduce_kernel(float* x, int ldx, 
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = i * 256 + tid;
-    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int cc = min(c, nv - 1) * 4;  // unconditional clamped loads
+    v[i] = *(const float4*)(xr + cc);
+    for (int s = 0; s < nslab; ++s) {
+      const float4 q = *(const float4*)(slabs + s * slab_stride + (int64_t)row * ld_slab + cc);
+      v[i].x += q.x; v[i].y += q.y; v[i].z += q.z; v[i].w += q.w;
+    }
     if (c < nv) {
-      v[i] = *(const float4*)(xr + c * 4);
-      for (int s = 0; s < nslab; ++s) {
-        const float4 q = *(const float4*)(slabs + s * slab_stride + (int64_t)row * ld_slab + c * 4);
-        v[i].x += q.x; v[i].y += q.y; v[i].z += q.z; v[i].w += q.w;
-      }
       if (nslab > 0) *(float4*)(xr + c * 4) = v[i];
       ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
     }
@@ -200,28 +293,68 @@ __global__ __launch_bounds__(256) void rope_append_kernel(const float* qkv, int 
 
 // =========================================================================================== decode attention
 constexpr float NEG_BIG = -1e30f;
+constexpr int DA_WAVES = 8;
 
 template <int DT>
-__global__ __launch_bounds__(256) void decode_attn_kernel(const uint16_t* q, int ldq, const uint16_t* kcache, const uint16_t* vtcache,
+__global__ __launch_bounds__(512) void decode_attn_kernel(const uint16_t* q, int ldq, uint16_t* kcache, uint16_t* vtcache,
                                                           const int32_t* ctx_len, int ctx_add, uint16_t* out, int ldo, int Hq, int Hkv,
-                                                          int ctx_max, float scale) {
-  __shared__ float s_m[4][16], s_l[4][16];
-  __shared__ float s_o[4][64][17];  // [wave][d][query col] (+1 pad)
+                                                          int ctx_max, float scale, const float* qkv, int ldqkv, const float* inv_freq) {
+  __shared__ float s_m[DA_WAVES][16], s_l[DA_WAVES][16];
+  __shared__ float s_o[DA_WAVES][64][17];  // [wave][d][query col] (+1 pad)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lq = lane & 15, lg = lane >> 4;
   const int hk = blockIdx.x, b = blockIdx.y;
   const int G = Hq / Hkv;  // query heads per kv head (<= 16)
-  const int ctx = min(ctx_len[b] + ctx_add, ctx_max);
-  const uint16_t* Kb = kcache + ((int64_t)b * Hkv + hk) * ctx_max * 64;
-  const uint16_t* Vb = vtcache + ((int64_t)b * Hkv + hk) * 64 * ctx_max;
+  const int pos = ctx_len[b];
+  const int ctx = min(pos + ctx_add, ctx_max);
+  uint16_t* Kb = kcache + ((int64_t)b * Hkv + hk) * ctx_max * 64;
+  uint16_t* Vb = vtcache + ((int64_t)b * Hkv + hk) * 64 * ctx_max;
 
-  // Q fragments: column lq = query head hk*G + lq (zero beyond the group)
-  uint4 qf[2];
+  // Q fragments: column lq = query head hk*G + lq (zero beyond the group); d chunks (ks*4 + lg)*8
+  uint4 qf[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+  if (qkv) {
+    // fused RoPE (HF rotate_half: pairs (d, d+32)); a lane owns d in [8 lg, 8 lg + 8) and the partners + 32
+    const float* row = qkv + (int64_t)b * ldqkv;
+    if (lq < G) {
+      const float* src = row + (hk * G + lq) * 64 + 8 * lg;
+      float lo[8], hi[8];
+      const float* cs_row = inv_freq + (int64_t)min(pos, ctx_max - 1) * 64;  // [pos][cos 32 | sin 32] table
+      const float4 c0 = *(const float4*)(cs_row + 8 * lg), c1 = *(const float4*)(cs_row + 8 * lg + 4);
+      const float4 s0 = *(const float4*)(cs_row + 32 + 8 * lg), s1 = *(const float4*)(cs_row + 32 + 8 * lg + 4);
+      const float4 a0 = *(const float4*)(src), a1 = *(const float4*)(src + 4);
+      const float4 b0 = *(const float4*)(src + 32), b1 = *(const float4*)(src + 36);
+      const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+      const float sn_[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+      const float x1_[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      const float x2_[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    qf[ks] = make_uint4(0, 0, 0, 0);
-    if (lq < G) qf[ks] = *(const uint4*)(q + (int64_t)b * ldq + (hk * G + lq) * 64 + (ks * 4 + lg) * 8);
+      for (int j = 0; j < 8; ++j) {
+        lo[j] = x1_[j] * cc[j] - x2_[j] * sn_[j];
+        hi[j] = x2_[j] * cc[j] + x1_[j] * sn_[j];
+      }
+      qf[0] = make_uint4(pack2<DT>(lo[0], lo[1]), pack2<DT>(lo[2], lo[3]), pack2<DT>(lo[4], lo[5]), pack2<DT>(lo[6], lo[7]));
+      qf[1] = make_uint4(pack2<DT>(hi[0], hi[1]), pack2<DT>(hi[2], hi[3]), pack2<DT>(hi[4], hi[5]), pack2<DT>(hi[6], hi[7]));
+    }
+    // append K (roped) and V^T of this kv head at position pos: wave 0 lanes 0..31 -> K pairs, wave 1 -> V
+    if (pos < ctx_max) {
+      if (wid == 0 && lane < 32) {
+        const float* ks_ = row + Hq * 64 + hk * 64;
+        const float cs = inv_freq[(int64_t)pos * 64 + lane], sn = inv_freq[(int64_t)pos * 64 + 32 + lane];
+        const float x1 = ks_[lane], x2 = ks_[lane + 32];
+        Kb[(int64_t)pos * 64 + lane] = Elem16<DT>::from_f32(x1 * cs - x2 * sn);
+        Kb[(int64_t)pos * 64 + lane + 32] = Elem16<DT>::from_f32(x2 * cs + x1 * sn);
+      } else if (wid == 1) {
+        Vb[(int64_t)lane * ctx_max + pos] = Elem16<DT>::from_f32(row[(Hq + Hkv) * 64 + hk * 64 + lane]);
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      if (lq < G) qf[ks] = *(const uint4*)(q + (int64_t)b * ldq + (hk * G + lq) * 64 + (ks * 4 + lg) * 8);
   }
+
   f32x4_t oacc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) oacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -229,20 +362,34 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const uint16_t* q, int
   const float sc = scale * 1.4426950408889634f;
   const int ntiles = (ctx + 63) >> 6;
 
-  for (int t = wid; t < ntiles; t += 4) {
+  for (int t = wid; t < ntiles; t += DA_WAVES) {
     const int j0 = t << 6;
+    // issue every load of the tile up front (K: 8 x 16 B, V^T: 16 x 8 B per lane)
+    uint4 kf[4][2];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      // unconditional: rows beyond ctx hold finite stale / zero data and their scores are masked below
+      const int key = min(j0 + kt * 16 + lq, ctx_max - 1);
+      kf[kt][0] = *(const uint4*)(Kb + (int64_t)key * 64 + lg * 8);
+      kf[kt][1] = *(const uint4*)(Kb + (int64_t)key * 64 + 32 + lg * 8);
+    }
+    uint2 vf[4][2][2];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const uint16_t* vrow = Vb + (int64_t)(dt * 16 + lq) * ctx_max + j0 + 4 * lg;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        // the cache is zero-initialised and only ever holds finite values: stale keys beyond ctx meet P == 0
+        vf[dt][s2][0] = *(const uint2*)(vrow + 32 * s2);
+        vf[dt][s2][1] = *(const uint2*)(vrow + 32 * s2 + 16);
+      }
+    }
     f32x4_t sacc[4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      const int key = j0 + kt * 16 + lq;
-      uint4 k0 = make_uint4(0, 0, 0, 0), k1 = k0;
-      if (key < ctx) {
-        k0 = *(const uint4*)(Kb + (int64_t)key * 64 + lg * 8);
-        k1 = *(const uint4*)(Kb + (int64_t)key * 64 + 32 + lg * 8);
-      }
       f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      a = mfma_block<DT>(k0, qf[0], a);
-      a = mfma_block<DT>(k1, qf[1], a);
+      a = mfma_block<DT>(kf[kt][0], qf[0], a);
+      a = mfma_block<DT>(kf[kt][1], qf[1], a);
       sacc[kt] = a;
     }
     float mx = NEG_BIG;
@@ -281,20 +428,12 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const uint16_t* q, int
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       oacc[dt][0] *= alpha; oacc[dt][1] *= alpha; oacc[dt][2] *= alpha; oacc[dt][3] *= alpha;
-      const uint16_t* vrow = Vb + (int64_t)(dt * 16 + lq) * ctx_max + j0 + 4 * lg;
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        // keys j0 + 32 s2 + 4 lg + {0..3} and +16: the cache is zero-initialised, stale entries beyond ctx are finite
-        // and meet P == 0; guard only the buffer end
-        uint2 lo = make_uint2(0, 0), hi = lo;
-        const int kk = j0 + 32 * s2 + 4 * lg;
-        if (kk + 4 <= ctx_max) lo = *(const uint2*)(vrow + 32 * s2);
-        if (kk + 20 <= ctx_max) hi = *(const uint2*)(vrow + 32 * s2 + 16);
-        oacc[dt] = mfma_block<DT>(make_uint4(lo.x, lo.y, hi.x, hi.y), pf[s2], oacc[dt]);
-      }
+      for (int s2 = 0; s2 < 2; ++s2)
+        oacc[dt] = mfma_block<DT>(make_uint4(vf[dt][s2][0].x, vf[dt][s2][0].y, vf[dt][s2][1].x, vf[dt][s2][1].y), pf[s2], oacc[dt]);
     }
   }
-  // ---- merge the four waves (log-sum-exp)
+  // ---- merge the waves (log-sum-exp)
   float l = lrun;
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
@@ -304,22 +443,27 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const uint16_t* q, int
 #pragma unroll
     for (int r = 0; r < 4; ++r) s_o[wid][dt * 16 + 4 * lg + r][lq] = oacc[dt][r];
   __syncthreads();
-  // thread -> (query col c = tid / 16 < 16, 4 d values)
-  const int c = tid >> 4, d0 = (tid & 15) * 4;
-  if (c < G) {
-    const float m0 = s_m[0][c], m1 = s_m[1][c], m2 = s_m[2][c], m3 = s_m[3][c];
-    const float mm = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-    const float w0 = exp2f(m0 - mm), w1 = exp2f(m1 - mm), w2 = exp2f(m2 - mm), w3 = exp2f(m3 - mm);
-    const float lt = s_l[0][c] * w0 + s_l[1][c] * w1 + s_l[2][c] * w2 + s_l[3][c] * w3;
-    const float inv = lt > 0.f ? 1.f / lt : 0.f;
-    float o[4];
+  // thread -> (query col c = tid / 16, 4 d values); 16 cols x 16 d-quads = 256 threads
+  if (tid < 256) {
+    const int c = tid >> 4, d0 = (tid & 15) * 4;
+    if (c < G) {
+      float mm = NEG_BIG;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      o[r] = (s_o[0][d0 + r][c] * w0 + s_o[1][d0 + r][c] * w1 + s_o[2][d0 + r][c] * w2 + s_o[3][d0 + r][c] * w3) * inv;
-    uint2 u;
-    u.x = pack2<DT>(o[0], o[1]);
-    u.y = pack2<DT>(o[2], o[3]);
-    *(uint2*)(out + (int64_t)b * ldo + (hk * G + c) * 64 + d0) = u;
+      for (int w_ = 0; w_ < DA_WAVES; ++w_) mm = fmaxf(mm, s_m[w_][c]);
+      float lt = 0.f, o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w_ = 0; w_ < DA_WAVES; ++w_) {
+        const float ww = exp2f(s_m[w_][c] - mm);
+        lt += s_l[w_][c] * ww;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] += s_o[w_][d0 + r][c] * ww;
+      }
+      const float inv = lt > 0.f ? 1.f / lt : 0.f;
+      uint2 u;
+      u.x = pack2<DT>(o[0] * inv, o[1] * inv);
+      u.y = pack2<DT>(o[2] * inv, o[3] * inv);
+      *(uint2*)(out + (int64_t)b * ldo + (hk * G + c) * 64 + d0) = u;
+    }
   }
 }
 
@@ -361,7 +505,8 @@ __global__ __launch_bounds__(256) void sample_kernel(const cv_sample_params p) {
 #pragma unroll
   for (int j = 0; j < SV_PER; ++j) {
     const int i = tid + 256 * j;
-    v[j] = i < V ? lg[i] : NEG_BIG;
+    const float t = lg[min(i, V - 1)];  // unconditional clamped load
+    v[j] = i < V ? t : NEG_BIG;
     mx = fmaxf(mx, v[j]);
   }
   mx = wave_max(mx);
@@ -501,8 +646,11 @@ __global__ __launch_bounds__(256) void sample_kernel(const cv_sample_params p) {
   else if (token == p.eos) fin = 1;
   else if (token < p.eos) emit = true;
   if (emit && n_em >= p.out_ld) { emit = false; fin = 2; }
-  if (emit) {
-    const float* e = p.emb_table + (int64_t)token * p.emb_dim;
+  // next-step input embedding.  Emitted id -> its embedding; skipped id (> EOS, llm.py:869-870 `continue`) -> the
+  // previous input again = embedding of the last emitted id (the residual stream has overwritten x meanwhile).
+  int next_in = emit ? token : ((!fin && n_em > 0) ? p.out_tokens[(int64_t)b * p.out_ld + n_em - 1] : -1);
+  if (next_in >= 0) {
+    const float* e = p.emb_table + (int64_t)next_in * p.emb_dim;
     for (int i = tid; i < p.emb_dim; i += 256) p.x[(int64_t)b * p.ldx + i] = e[i];
   }
   if (tid == 0) {
@@ -544,20 +692,45 @@ extern "C" int cv_pack_skinny(const void* W, void* Wp, int32_t N, int32_t K, int
 extern "C" int cv_skinny_gemm(const cv_skinny_params* pp, void* stream) {
   if (!pp) return CV_ERR_ARG;
   cv_skinny_params p = *pp;
-  if (p.M <= 0 || p.M > 16 || p.N <= 0 || p.K <= 0 || (p.K & 31) || !p.A || !p.Wp || (p.lda & 7)) return CV_ERR_ARG;
+  const bool norm = p.ngamma != nullptr;
+  if (p.M <= 0 || p.M > 16 || p.N <= 0 || p.K <= 0 || (p.K & 31) || !p.Wp) return CV_ERR_ARG;
+  if (!norm && (!p.A || (p.lda & 7))) return CV_ERR_ARG;
+  if (norm) {
+    if (!p.nx || (p.K & 63) || p.K > 1024 || (p.ldnx & 3) || p.nx_out == p.nx) return CV_ERR_ARG;
+    if (p.n_nslab > 0 && (!p.nslabs || (p.ld_nslab & 3) || (p.nslab_stride & 3))) return CV_ERR_ARG;
+  }
   if (p.ksplit <= 0) p.ksplit = 1;
   const int ntiles = (p.N + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
+  const size_t img = norm ? (size_t)(p.K >> 5) * 1024 : 0;
+  if (norm && p.n_nslab > 4) return CV_ERR_ARG;
+  const int nm = !norm ? 0 : (p.n_nslab > 0 ? 2 : 1);
+  const int tpr = p.M <= 4 ? 64 : (p.M <= 8 ? 32 : 16);
+#define SK_LAUNCH(TPW_, NM_, TPR_) \
+  DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, TPW_, NM_, TPR_>), grid, dim3(256), lds, st, p))
+#define SK_NORM(TPW_)                                                       \
+  do {                                                                      \
+    if (nm == 0) { SK_LAUNCH(TPW_, 0, 16); }                                \
+    else if (nm == 1) {                                                     \
+      if (tpr == 64) { SK_LAUNCH(TPW_, 1, 64); } else if (tpr == 32) { SK_LAUNCH(TPW_, 1, 32); } else { SK_LAUNCH(TPW_, 1, 16); } \
+    } else {                                                                \
+      if (tpr == 64) { SK_LAUNCH(TPW_, 2, 64); } else if (tpr == 32) { SK_LAUNCH(TPW_, 2, 32); } else { SK_LAUNCH(TPW_, 2, 16); } \
+    }                                                                       \
+  } while (0)
   if (p.mode == 2) {
     if (p.ksplit != 1 || (ntiles & 1) || !p.out_act || (p.ldoa & 3)) return CV_ERR_ARG;
     dim3 grid(ntiles / 2, 1);
-    DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, 2>), grid, dim3(256), 0, st, p));
+    const size_t lds = 4 * 2 * 64 * 4 * sizeof(float) + img;
+    SK_NORM(2);
   } else {
     if (!p.out_f32) return CV_ERR_ARG;
     if (p.mode == 1 && p.ksplit != 1) return CV_ERR_ARG;
     dim3 grid(ntiles, p.ksplit);
-    DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, 1>), grid, dim3(256), 0, st, p));
+    const size_t lds = 4 * 1 * 64 * 4 * sizeof(float) + img;
+    SK_NORM(1);
   }
+#undef SK_NORM
+#undef SK_LAUNCH
   CV_CHECK_LAUNCH();
   return CV_OK;
 }
@@ -589,13 +762,15 @@ extern "C" int cv_rope_append(const float* qkv, int32_t ldqkv, const int32_t* po
 
 extern "C" int cv_decode_attention(const void* q, int32_t ldq, const void* kcache, const void* vtcache, const int32_t* ctx_len,
                                    int32_t ctx_add, void* out, int32_t ldo, int32_t B, int32_t Hq, int32_t Hkv, int32_t ctx_max,
-                                   float scale, int32_t dtype, void* stream) {
-  if (!q || !kcache || !vtcache || !ctx_len || !out || B <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || Hq / Hkv > 16) return CV_ERR_ARG;
-  if ((ldq & 7) || (ldo & 3) || (ctx_max & 7)) return CV_ERR_ARG;
+                                   float scale, int32_t dtype, const float* qkv, int32_t ldqkv, const float* inv_freq, void* stream) {
+  if (!kcache || !vtcache || !ctx_len || !out || B <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || Hq / Hkv > 16) return CV_ERR_ARG;
+  if (!qkv && (!q || (ldq & 7))) return CV_ERR_ARG;
+  if (qkv && (!inv_freq || ldqkv < (Hq + 2 * Hkv) * 64)) return CV_ERR_ARG;
+  if ((ldo & 3) || (ctx_max & 63)) return CV_ERR_ARG;
   dim3 grid(Hkv, B);
-  DISPATCH_16(dtype, hipLaunchKernelGGL(decode_attn_kernel<DT>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)q, ldq,
-                                        (const uint16_t*)kcache, (const uint16_t*)vtcache, ctx_len, ctx_add, (uint16_t*)out, ldo, Hq, Hkv,
-                                        ctx_max, scale));
+  DISPATCH_16(dtype, hipLaunchKernelGGL(decode_attn_kernel<DT>, grid, dim3(512), 0, (hipStream_t)stream, (const uint16_t*)q, ldq,
+                                        (uint16_t*)kcache, (uint16_t*)vtcache, ctx_len, ctx_add, (uint16_t*)out, ldo, Hq, Hkv,
+                                        ctx_max, scale, qkv, ldqkv, inv_freq));
   CV_CHECK_LAUNCH();
   return CV_OK;
 }

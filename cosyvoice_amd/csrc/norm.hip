@@ -14,15 +14,14 @@ __global__ __launch_bounds__(256) void norm_kernel(const cv_norm_params p) {
   float4 v[MAXV];
   const int nv = p.dim >> 2;
   float s = 0.f;
+  // unconditional clamped loads (a load under a per-element branch is waited for individually), masked afterwards
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = i * 64 + lane;
-    if (c < nv) {
-      v[i] = *(const float4*)(x + c * 4);
-      s += v[i].x + v[i].y + v[i].z + v[i].w;
-    } else {
-      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    const float4 t = *(const float4*)(x + min(c, nv - 1) * 4);
+    const float mk = c < nv ? 1.f : 0.f;
+    v[i] = make_float4(t.x * mk, t.y * mk, t.z * mk, t.w * mk);
+    s += v[i].x + v[i].y + v[i].z + v[i].w;
   }
   float mean = 0.f;
   if (!p.rms) mean = wave_sum(s) / (float)p.dim;
@@ -37,19 +36,25 @@ __global__ __launch_bounds__(256) void norm_kernel(const cv_norm_params p) {
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)p.dim + p.eps);
   const float* add = p.add ? p.add + (int64_t)(row / p.rows_per_group) * p.add_ld : nullptr;
+  const bool has_g = p.gamma != nullptr, has_b = p.beta != nullptr, has_a = add != nullptr;  // wave-uniform
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = i * 64 + lane;
+    const int cc = min(c, nv - 1) * 4;
+    // parameter vectors loaded as float4, unconditionally within the uniform branches
+    float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f), a4 = b4;
+    if (has_g) g4 = *(const float4*)(p.gamma + cc);
+    if (has_b) b4 = *(const float4*)(p.beta + cc);
+    if (has_a) a4 = *(const float4*)(add + cc);
     if (c >= nv) continue;
     const int col = c * 4;
     float o[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+    const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w}, aa[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float y = (o[r] - mean) * rstd;
-      if (p.gamma) y *= p.gamma[col + r];
-      if (p.beta) y += p.beta[col + r];
+      float y = (o[r] - mean) * rstd * gg[r] + bb[r];
       if (p.act == CV_ACT_MISH) y = act_mish(y);
-      if (add) y += add[col + r];
+      y += aa[r];
       o[r] = y * p.out_scale;
     }
     if (p.out_f32) *(float4*)(p.out_f32 + (int64_t)row * p.ldo32 + col) = make_float4(o[0], o[1], o[2], o[3]);

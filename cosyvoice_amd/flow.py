@@ -63,12 +63,16 @@ class UpsampleConformerEncoder:
             a = f"{name}.self_attn."
             bq = sd[a + "linear_q.bias"].float()
             wq = sd[a + "linear_q.weight"].float()
-            wqkv = torch.cat([wq, wq, sd[a + "linear_k.weight"].float(), sd[a + "linear_v.weight"].float()], 0)
-            bqkv = torch.cat([bq + sd[a + "pos_bias_u"].float().reshape(-1), bq + sd[a + "pos_bias_v"].float().reshape(-1),
-                              sd[a + "linear_k.bias"].float(), sd[a + "linear_v.bias"].float()], 0)
-            return dict(wqkv=wqkv.to(device=self.device, dtype=self.dtype).contiguous(),
-                        bqkv=bqkv.to(device=self.device).contiguous(),
-                        wpos=P.w(a + "linear_pos.weight"), wout=P.w(a + "linear_out.weight"), bout=P.f32(a + "linear_out.bias"),
+            wqqk = torch.cat([wq, wq, sd[a + "linear_k.weight"].float()], 0)
+            bqqk = torch.cat([bq + sd[a + "pos_bias_u"].float().reshape(-1), bq + sd[a + "pos_bias_v"].float().reshape(-1),
+                              sd[a + "linear_k.bias"].float()], 0)
+            # softmax rows sum to 1, so P.(V + 1 b_v^T) = P.V + b_v: the value bias is folded into linear_out's bias
+            wout = sd[a + "linear_out.weight"].float()
+            bout = sd[a + "linear_out.bias"].float() + wout @ sd[a + "linear_v.bias"].float()
+            return dict(wqqk=wqqk.to(device=self.device, dtype=self.dtype).contiguous(),
+                        bqqk=bqqk.to(device=self.device).contiguous(), wv=P.w(a + "linear_v.weight"),
+                        wpos=P.w(a + "linear_pos.weight"), wout=P.w(a + "linear_out.weight"),
+                        bout=bout.to(device=self.device).contiguous(),
                         w1=P.w(f"{name}.feed_forward.w_1.weight"), b1=P.f32(f"{name}.feed_forward.w_1.bias"),
                         w2=P.w(f"{name}.feed_forward.w_2.weight"), b2=P.f32(f"{name}.feed_forward.w_2.bias"),
                         g_mha=P.f32(f"{name}.norm_mha.weight"), b_mha=P.f32(f"{name}.norm_mha.bias"),
@@ -125,7 +129,7 @@ class UpsampleConformerEncoder:
             Tp = _round_up(T, 8)
             ldb = _round_up(2 * T - 1, 4)
             ws[tag] = dict(T=T, Tp=Tp, ldb=ldb, xs=e(R, T, D), xn=e(R, T, D, dtype=dt), lin=e(R, T, D),
-                           q=e(R, T, 2 * D, dtype=dt), k=e(R, T, D, dtype=dt), vt=torch.zeros(R, H, 64, Tp, device=dev, dtype=dt),
+                           q=e(R, T, 3 * D, dtype=dt), vt=torch.zeros(R, H, 64, Tp, device=dev, dtype=dt),
                            bd=e(R, H, T, ldb), ao=e(R, T, D, dtype=dt), ff=e(R, T, U, dtype=dt), xa=e(R, T, D, dtype=dt))
         ws["tok"] = e(R, N, D, dtype=dt)
         ws["t1"] = e(R, N, D, dtype=dt)
@@ -141,15 +145,15 @@ class UpsampleConformerEncoder:
         xs = w["xs"]
         xs2 = xs.view(R * T, D)
         ops.layernorm(xs2, l["g_mha"], l["b_mha"], 1e-12, out_act=w["xn"].view(R * T, D))
-        ops.gemm(w["xn"], l["wqkv"], T, 4 * D, D, batch=R, a_bs=(T * D, 0), lda=D, bias=l["bqkv"], out_act=w["q"],
-                 oa_bs=(T * 2 * D, 0), ldoa=2 * D,
-                 qkv=dict(q_cols=2 * D, k_cols=D, k_out=w["k"], k_bs=T * D, ldk=D, vt_out=w["vt"], vt_heads=H, vt_ld=Tp))
+        # [q+u | q+v | k] row-major in one GEMM (ld 3D); V^T as the swapped product Wv . xn^T
+        ops.linear(w["xn"].view(R * T, D), l["wqqk"], bias=l["bqqk"], out_act=w["q"].view(R * T, 3 * D))
+        ops.gemm(l["wv"], w["xn"], D, T, D, batch=R, lda=D, w_bs=(T * D, 0), ldw=D, out_act=w["vt"], oa_bs=(D * Tp, 0), ldoa=Tp)
         # matrix_bd = (q + pos_bias_v) . p^T per head, pre-scaled by 1/sqrt(dk) (attention.py:317-327)
         scale = 1.0 / math.sqrt(D // H)
-        ops.gemm(w["q"][:, :, D:], p_l, T, 2 * T - 1, 64, batch=R * H, batch_inner=H, a_bs=(64, T * 2 * D), lda=2 * D,
+        ops.gemm(w["q"][:, :, D:], p_l, T, 2 * T - 1, 64, batch=R * H, batch_inner=H, a_bs=(64, T * 3 * D), lda=3 * D,
                  w_bs=(64, 0), ldw=D, out_scale=scale, out_f32=w["bd"], o32_bs=(T * ldb, H * T * ldb), ldo32=ldb)
-        ops.attention(w["q"], w["k"], w["vt"], w["ao"], B=R, H=H, Hkv=H, Tq=T, Tk=T, scale=scale, q_bs=T * 2 * D, ldq=2 * D,
-                      k_bs=T * D, ldk=D, vt_ld=Tp, o_bs=T * D, ldo=D, klen=klen, chunk=chunk,
+        ops.attention(w["q"], w["q"][:, :, 2 * D:], w["vt"], w["ao"], B=R, H=H, Hkv=H, Tq=T, Tk=T, scale=scale, q_bs=T * 3 * D,
+                      ldq=3 * D, k_bs=T * 3 * D, ldk=3 * D, vt_ld=Tp, o_bs=T * D, ldo=D, klen=klen, chunk=chunk,
                       bias=w["bd"].view(-1)[T - 1:], bias_bs=H * T * ldb, bias_hs=T * ldb, bias_ld=ldb - 1)
         ops.linear(w["ao"].view(R * T, D), l["wout"], bias=l["bout"], res=xs2, out_f32=xs2)
         ops.layernorm(xs2, l["g_ff"], l["b_ff"], 1e-12, out_act=w["xn"].view(R * T, D))
@@ -218,10 +222,9 @@ class ConditionalDecoder:
                         wr=P.conv(f"{name}.res_conv.weight"), br=P.f32(f"{name}.res_conv.bias"))
 
         def tblock(name):
-            wqkv = torch.cat([sd[f"{name}.attn1.to_q.weight"].float(), sd[f"{name}.attn1.to_k.weight"].float(),
-                              sd[f"{name}.attn1.to_v.weight"].float()], 0)
+            wqk = torch.cat([sd[f"{name}.attn1.to_q.weight"].float(), sd[f"{name}.attn1.to_k.weight"].float()], 0)
             return dict(g1=P.f32(f"{name}.norm1.weight"), b1=P.f32(f"{name}.norm1.bias"),
-                        wqkv=wqkv.to(device=self.device, dtype=self.dtype).contiguous(),
+                        wqk=wqk.to(device=self.device, dtype=self.dtype).contiguous(), wv=P.w(f"{name}.attn1.to_v.weight"),
                         wo=P.w(f"{name}.attn1.to_out.0.weight"), bo=P.f32(f"{name}.attn1.to_out.0.bias"),
                         g3=P.f32(f"{name}.norm3.weight"), b3=P.f32(f"{name}.norm3.bias"),
                         wf1=P.w(f"{name}.ff.net.0.proj.weight"), bf1=P.f32(f"{name}.ff.net.0.proj.bias"),
@@ -278,7 +281,7 @@ class ConditionalDecoder:
         e = lambda *s, dtype=torch.float32: torch.empty(*s, device=dev, dtype=dtype)
         Tp = _round_up(T, 8)
         ws = dict(T=T, Tp=Tp, xin=e(R, T, cfg.est_in_channels, dtype=dt), c32a=e(R, T, C), c32b=e(R, T, C), h1=e(R, T, C, dtype=dt),
-                  x32=e(R, T, C), xn=e(R, T, C, dtype=dt), q=e(R, T, inner, dtype=dt), k=e(R, T, inner, dtype=dt),
+                  x32=e(R, T, C), xn=e(R, T, C, dtype=dt), qk=e(R, T, 2 * inner, dtype=dt),
                   vt=torch.zeros(R, cfg.est_heads, 64, Tp, device=dev, dtype=dt), ao=e(R, T, inner, dtype=dt),
                   ff=e(R, T, ff, dtype=dt), cat=e(R, T, 2 * C, dtype=dt), d=e(R, T, C, dtype=dt), v=e(R, T, cfg.output_size))
         self._ws[key] = ws
@@ -306,11 +309,12 @@ class ConditionalDecoder:
         rows = R * T
         x2 = ws["x32"].view(rows, C)
         ops.layernorm(x2, tb["g1"], tb["b1"], 1e-5, out_act=ws["xn"].view(rows, C))
-        ops.gemm(ws["xn"], tb["wqkv"], T, 3 * inner, C, batch=R, a_bs=(T * C, 0), lda=C, out_act=ws["q"], oa_bs=(T * inner, 0),
-                 ldoa=inner, qkv=dict(q_cols=inner, k_cols=inner, k_out=ws["k"], k_bs=T * inner, ldk=inner, vt_out=ws["vt"],
-                                      vt_heads=H, vt_ld=Tp))
-        ops.attention(ws["q"], ws["k"], ws["vt"], ws["ao"], B=R, H=H, Hkv=H, Tq=T, Tk=T, scale=cfg.est_head_dim ** -0.5,
-                      q_bs=T * inner, ldq=inner, k_bs=T * inner, ldk=inner, vt_ld=Tp, o_bs=T * inner, ldo=inner, klen=klen)
+        # Q | K row-major in one GEMM; V^T directly as the swapped product Wv . xn^T (rows = head*64 + d, keys contiguous)
+        ops.linear(ws["xn"].view(rows, C), tb["wqk"], out_act=ws["qk"].view(rows, 2 * inner))
+        ops.gemm(tb["wv"], ws["xn"], inner, T, C, batch=R, lda=C, w_bs=(T * C, 0), ldw=C, out_act=ws["vt"],
+                 oa_bs=(inner * Tp, 0), ldoa=Tp)
+        ops.attention(ws["qk"], ws["qk"][:, :, inner:], ws["vt"], ws["ao"], B=R, H=H, Hkv=H, Tq=T, Tk=T, scale=cfg.est_head_dim ** -0.5,
+                      q_bs=T * 2 * inner, ldq=2 * inner, k_bs=T * 2 * inner, ldk=2 * inner, vt_ld=Tp, o_bs=T * inner, ldo=inner, klen=klen)
         ops.linear(ws["ao"].view(rows, inner), tb["wo"], bias=tb["bo"], res=x2, out_f32=x2)
         ops.layernorm(x2, tb["g3"], tb["b3"], 1e-5, out_act=ws["xn"].view(rows, C))
         ops.linear(ws["xn"].view(rows, C), tb["wf1"], bias=tb["bf1"], act=ops.ACT_GELU, out_act=ws["ff"].view(rows, ff))

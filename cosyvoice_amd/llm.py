@@ -89,6 +89,8 @@ class Qwen2LM:
         self.p_dec = ops.pack_skinny(w16(sd["llm_decoder.weight"]))
         inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, cfg.head_dim, 2, dtype=torch.float32) / cfg.head_dim))
         self.inv_freq = inv.to(dev).contiguous()
+        ang = torch.arange(self.ctx_max, dtype=torch.float32)[:, None] * inv[None, :]
+        self.rope_table = torch.cat([ang.cos(), ang.sin()], dim=1).to(dev).contiguous()  # [ctx_max][cos 32 | sin 32]
         self._alloc_state()
         self._loaded = True
         return self
@@ -100,7 +102,7 @@ class Qwen2LM:
         z = lambda *s, dtype=torch.float32: torch.zeros(*s, device=dev, dtype=dtype)
         self.Vpad = _round_up(cfg.out_vocab, 16)
         MB = self.max_batch
-        self.st = dict(x=z(16, H), xn=z(16, H, dtype=dt), qkv=z(16, qkv_dim), q=z(16, cfg.q_dim, dtype=dt),
+        self.st = dict(x=z(16, H), x2=z(16, H), xn=z(16, H, dtype=dt), qkv=z(16, qkv_dim), q=z(16, cfg.q_dim, dtype=dt),
                        ao=z(16, cfg.q_dim, dtype=dt), h=z(16, I, dtype=dt), slabs=z(self.DOWN_KSPLIT, 16, H),
                        logits=z(16, self.Vpad), pos=z(16, dtype=torch.int32), step=z(16, dtype=torch.int32),
                        n_emitted=z(16, dtype=torch.int32), finished=z(16, dtype=torch.int32), min_len=z(16, dtype=torch.int32),
@@ -136,21 +138,22 @@ class Qwen2LM:
         qkv_dim = cfg.q_dim + 2 * cfg.kv_dim
         KS = self.DOWN_KSPLIT
         scale = 1.0 / math.sqrt(cfg.head_dim)
+        # residual stream ping-pongs between x (even layers) and x2 (odd): the fused prologue of the QKV kernel reads
+        # cur (+ the previous layer's down-proj slabs) and its workgroup (0,0) writes the summed residual to nxt
+        cur, nxt = st["x"], st["x2"]
         for li, lay in enumerate(self.layers):
-            if li == 0:
-                ops.rmsnorm_reduce(st["x"], lay["g_in"], cfg.rms_eps, st["xn"], B)
-            else:
-                ops.rmsnorm_reduce(st["x"], lay["g_in"], cfg.rms_eps, st["xn"], B, slabs=st["slabs"], nslab=KS, slab_stride=16 * H, ld_slab=H)
-            ops.skinny_gemm(st["xn"], lay["p_qkv"], B, qkv_dim, H, bias=lay["bqkv"], out_f32=st["qkv"], ldo=qkv_dim)
-            ops.rope_append(st["qkv"], st["pos"], B, 1, cfg.num_heads, cfg.num_kv_heads, self.inv_freq, st["q"], self.kcache[li],
-                            self.vtcache[li], self.ctx_max)
+            nrm = dict(x=cur, gamma=lay["g_in"], eps=cfg.rms_eps, x_out=nxt)
+            if li > 0:
+                nrm.update(slabs=st["slabs"], nslab=KS, slab_stride=16 * H, ld_slab=H)
+            ops.skinny_gemm(st["xn"], lay["p_qkv"], B, qkv_dim, H, bias=lay["bqkv"], out_f32=st["qkv"], ldo=qkv_dim, norm=nrm)
             ops.decode_attention(st["q"], self.kcache[li], self.vtcache[li], st["pos"], 1, st["ao"], B, cfg.num_heads,
-                                 cfg.num_kv_heads, self.ctx_max, scale)
-            ops.skinny_gemm(st["ao"], lay["p_o"], B, H, cfg.q_dim, mode=1, out_f32=st["x"], ldo=H)
-            ops.rmsnorm_reduce(st["x"], lay["g_post"], cfg.rms_eps, st["xn"], B)
-            ops.skinny_gemm(st["xn"], lay["p_gu"], B, 2 * I, H, mode=2, out_act=st["h"], ldoa=I)
+                                 cfg.num_kv_heads, self.ctx_max, scale, qkv=st["qkv"], inv_freq=self.rope_table)
+            ops.skinny_gemm(st["ao"], lay["p_o"], B, H, cfg.q_dim, mode=1, out_f32=nxt, ldo=H)
+            ops.skinny_gemm(st["xn"], lay["p_gu"], B, 2 * I, H, mode=2, out_act=st["h"], ldoa=I,
+                            norm=dict(x=nxt, gamma=lay["g_post"], eps=cfg.rms_eps))
             ops.skinny_gemm(st["h"], lay["p_down"], B, H, I, ksplit=KS, out_f32=st["slabs"], ldo=H, slab_stride=16 * H)
-        ops.rmsnorm_reduce(st["x"], self.g_final, cfg.rms_eps, st["xn"], B, slabs=st["slabs"], nslab=KS, slab_stride=16 * H, ld_slab=H)
+            cur, nxt = nxt, cur
+        ops.rmsnorm_reduce(cur, self.g_final, cfg.rms_eps, st["xn"], B, slabs=st["slabs"], nslab=KS, slab_stride=16 * H, ld_slab=H)
         self._head_and_sample(B, use_forced, use_uniforms)
 
     def _step(self, B, use_forced, use_uniforms):

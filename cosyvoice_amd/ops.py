@@ -219,7 +219,10 @@ def pack_skinny(W, interleave=False):
     return Wp
 
 
-def skinny_gemm(A, Wp, M, N, K, *, bias=None, ksplit=1, mode=0, out_f32=None, ldo=0, slab_stride=0, out_act=None, ldoa=0):
+def skinny_gemm(A, Wp, M, N, K, *, bias=None, ksplit=1, mode=0, out_f32=None, ldo=0, slab_stride=0, out_act=None, ldoa=0,
+                norm=None):
+    """norm = dict(x=, gamma=, eps=, x_out=None, slabs=None, nslab=0, slab_stride=0, ld_slab=0): fused RMSNorm prologue
+    (A is then unused; pass any 16-bit tensor for the dtype)."""
     _req_cuda(A, Wp, bias, out_f32, out_act)
     p = L.SkinnyParams()
     p.dtype, p.M, p.N, p.K = L.TORCH_DT[A.dtype], M, N, K
@@ -227,6 +230,14 @@ def skinny_gemm(A, Wp, M, N, K, *, bias=None, ksplit=1, mode=0, out_f32=None, ld
     p.ksplit, p.mode = ksplit, mode
     p.out_f32, p.ldo, p.slab_stride = L.ptr(out_f32), ldo, slab_stride
     p.out_act, p.ldoa = L.ptr(out_act), ldoa
+    if norm is not None:
+        x = norm["x"]
+        _req_cuda(x, norm["gamma"], norm.get("x_out"), norm.get("slabs"))
+        p.nx, p.ldnx = x.data_ptr(), x.stride(0)
+        p.nslabs, p.n_nslab = L.ptr(norm.get("slabs")), norm.get("nslab", 0)
+        p.nslab_stride, p.ld_nslab = norm.get("slab_stride", 0), norm.get("ld_slab", 0)
+        p.ngamma, p.neps = norm["gamma"].data_ptr(), norm["eps"]
+        p.nx_out = L.ptr(norm.get("x_out"))
     L.check(L.lib().cv_skinny_gemm(C.byref(p), L.stream_ptr()), "cv_skinny_gemm")
 
 
@@ -245,12 +256,14 @@ def rope_append(qkv, pos_base, rows, rows_per_seq, Hq, Hkv, inv_freq, q_out, kca
                                    L.stream_ptr()), "cv_rope_append")
 
 
-def decode_attention(q, kcache, vtcache, ctx_len, ctx_add, out, B, Hq, Hkv, ctx_max, scale):
-    _req_cuda(q, kcache, vtcache, ctx_len, out)
+def decode_attention(q, kcache, vtcache, ctx_len, ctx_add, out, B, Hq, Hkv, ctx_max, scale, qkv=None, inv_freq=None):
+    """qkv (fp32 [B][ld]) + inv_freq: fused RoPE + KV append + attention (q then only carries the dtype)."""
+    _req_cuda(q, kcache, vtcache, ctx_len, out, qkv, inv_freq)
     L.check(L.lib().cv_decode_attention(C.c_void_p(q.data_ptr()), q.stride(0), C.c_void_p(kcache.data_ptr()),
                                         C.c_void_p(vtcache.data_ptr()), C.c_void_p(ctx_len.data_ptr()), ctx_add,
                                         C.c_void_p(out.data_ptr()), out.stride(0), B, Hq, Hkv, ctx_max, C.c_float(scale),
-                                        L.TORCH_DT[q.dtype], L.stream_ptr()), "cv_decode_attention")
+                                        L.TORCH_DT[q.dtype], C.c_void_p(L.ptr(qkv)), (qkv.stride(0) if qkv is not None else 0),
+                                        C.c_void_p(L.ptr(inv_freq)), L.stream_ptr()), "cv_decode_attention")
 
 
 def sample_ras(params):

@@ -178,6 +178,12 @@ typedef struct cv_skinny_params {
   int32_t ksplit, mode;
   float* out_f32; int32_t ldo; int64_t slab_stride;
   void* out_act; int32_t ldoa;
+  /* optional fused prologue (ngamma != NULL; A is then ignored): v[m][:] = nx[m][:] + sum_s nslabs[s][m][:];
+     A[m][:] = T(rmsnorm(v[m]) * ngamma); workgroup (0,0) also stores v to nx_out (must not alias nx). K <= 1024. */
+  const float* nx; int32_t ldnx;
+  const float* nslabs; int32_t n_nslab; int64_t nslab_stride; int32_t ld_nslab;
+  const float* ngamma; float neps;
+  float* nx_out;
 } cv_skinny_params;
 int cv_skinny_gemm(const cv_skinny_params* p, void* stream);
 /* W [N][K] row-major 16-bit (device) -> packed (device), N padded up to a multiple of 16 with zeros.
@@ -196,11 +202,14 @@ int cv_rope_append(const float* qkv, int32_t ldqkv, const int32_t* pos_base, int
                    int32_t ctx_max, int32_t dtype, void* stream);
 
 /* Single-query GQA attention over the KV cache: for sequence b, kv head hk, the Hq/Hkv query heads of the group
- * form the (<=16) columns of one MFMA tile; 4 waves split the keys and merge by log-sum-exp.
- * q [B][ldq] 16-bit (row b), ctx_len[b] keys valid; out [B][ldo] 16-bit. */
+ * form the (<=16) columns of one MFMA tile; 8 waves split the keys and merge by log-sum-exp.
+ * q [B][ldq] 16-bit (row b), ctx_len[b] + ctx_add keys valid; out [B][ldo] 16-bit.
+ * Fused form (qkv != NULL): q is ignored; the kernel first applies RoPE to row b of qkv fp32 [B][ldqkv]
+ * (= [q | k | v], position ctx_len[b]; inv_freq is then the table rope[ctx_max][64] = [cos 32 | sin 32] per position),
+ * appends K / V^T of its kv head to the caches, then attends (ctx_add = 1). */
 int cv_decode_attention(const void* q, int32_t ldq, const void* kcache, const void* vtcache, const int32_t* ctx_len,
                         int32_t ctx_add, void* out, int32_t ldo, int32_t B, int32_t Hq, int32_t Hkv, int32_t ctx_max,
-                        float scale, int32_t dtype, void* stream);
+                        float scale, int32_t dtype, const float* qkv, int32_t ldqkv, const float* inv_freq, void* stream);
 
 /* Repetition-aware sampling on device (utils/common.py:109-146 ras_sampling/nucleus_sampling/random_sampling,
  * llm/llm.py:806-821 sampling_ids, :861-874 loop bookkeeping).  One workgroup per sequence. */

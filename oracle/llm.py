@@ -136,12 +136,12 @@ def ras_sampling(weighted_scores, decoded_tokens, u_pair, top_p=0.8, top_k=25, w
     return top
 
 
-def sampling_ids(weighted_scores, decoded_tokens, ignore_eos: bool, eos: int, uniforms: Callable[[], tuple],
+def sampling_ids(weighted_scores, decoded_tokens, ignore_eos: bool, eos: int, uniforms: Callable[[int], tuple],
                  max_trials: int = 100) -> int:
-    # llm.py:806-821
+    # llm.py:806-821.  ``uniforms(trial)`` supplies the (nucleus, fallback) uniforms of redraw number ``trial``.
     num_trials = 0
     while True:
-        top = ras_sampling(weighted_scores, decoded_tokens, uniforms())
+        top = ras_sampling(weighted_scores, decoded_tokens, uniforms(num_trials))
         if (not ignore_eos) or top != eos:
             return top
         num_trials += 1
@@ -149,7 +149,7 @@ def sampling_ids(weighted_scores, decoded_tokens, ignore_eos: bool, eos: int, un
             raise RuntimeError("sampling reaches max_trials {} and still get eos when ignore_eos is True".format(max_trials))
 
 
-def lm_inference(sd, cfg: LlmConfig, text, prompt_text, prompt_speech_token, uniforms: Callable[[], tuple],
+def lm_inference(sd, cfg: LlmConfig, text, prompt_text, prompt_speech_token, uniforms: Callable[[int], tuple],
                  max_token_text_ratio=20, min_token_text_ratio=2, forced_tokens: Optional[List[int]] = None,
                  collect_logp: Optional[list] = None):
     """Qwen2LM.inference, llm.py:823-874.  Yields python ints.  ``forced_tokens`` teacher-forces the

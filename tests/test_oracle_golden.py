@@ -85,7 +85,7 @@ def test_llm_teacher_forced_logp(golden_dir):
     lp = []
     rnd = random.Random(0)
     toks = list(ol.lm_inference(sd, cfg, g["text"], g["prompt_text"], g["prompt_speech"],
-                                uniforms=lambda: (rnd.random(), rnd.random()), forced_tokens=forced, collect_logp=lp))
+                                uniforms=lambda t: (rnd.random(), rnd.random()), forced_tokens=forced, collect_logp=lp))
     assert toks == forced
     lp = torch.stack(lp)
     assert (lp - g["logps"][: lp.shape[0]]).abs().max().item() < 1e-4
