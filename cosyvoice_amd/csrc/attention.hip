@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const cv_attn_params p) {
     for (int i = 0; i < 2; ++i) {
       const int c = i * 256 + tid;
       const int r = c >> 3, dc = c & 7;
-      rk[i] = *(const uint4*)(Kp + (int64_t)min(j0 + r, key_max) * p.ldk + dc * 8);      // r = key, dc = d chunk
+      const int kr = ((c >> 6) << 3) + (c & 7), kdc = (c >> 3) & 7;  // K: lanes 0..7 on 8 keys of one d chunk (LDS write banks)
+      rk[i] = *(const uint4*)(Kp + (int64_t)min(j0 + kr, key_max) * p.ldk + kdc * 8);
       rv[i] = *(const uint4*)(Vt + (int64_t)r * p.vt_ld + min(j0 + dc * 8, vchunk_max));  // r = d row, dc = key chunk
     }
   };
@@ -78,8 +79,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const cv_attn_params p) {
     for (int i = 0; i < 2; ++i) {
       const int c = i * 256 + tid;
       const int r = c >> 3, dc = c & 7;
-      const uint32_t km = (tile_j0 + r < klen) ? 0xFFFFFFFFu : 0u;
-      *(uint4*)(sk + (((r >> 4) * 2 + (dc >> 2)) << 10) + ((dc & 3) << 8) + ((r & 15) << 4)) =
+      const int kr = ((c >> 6) << 3) + (c & 7), kdc = (c >> 3) & 7;
+      const uint32_t km = (tile_j0 + kr < klen) ? 0xFFFFFFFFu : 0u;
+      *(uint4*)(sk + (((kr >> 4) * 2 + (kdc >> 2)) << 10) + ((kdc & 3) << 8) + ((kr & 15) << 4)) =
           make_uint4(rk[i].x & km, rk[i].y & km, rk[i].z & km, rk[i].w & km);
       // zero every key >= klen of the V^T chunk (0 * garbage must not become NaN)
       const int nvalid = klen - (tile_j0 + dc * 8);

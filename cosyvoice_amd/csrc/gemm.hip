@@ -3,13 +3,16 @@
 // C[m][n] = epilogue( sum_k A[row(m,k)][ci(k)] * W[n][k] ),  A channels-last activations, W = [N][K] (torch Linear /
 // repacked Conv1d layout).  256 threads = 4 waves (2x2); each wave owns a (BM/2)x(BN/2) patch of 16x16 MFMA tiles.
 // K is consumed in tiles of 128 bytes per row (64 x 16-bit or 32 x f32): global -> registers (16-byte chunks, 8 lanes
-// per row = one full 128-byte line) -> LDS -> ds_read_b128 fragments -> MFMA.
+// per row = one full 128-byte line) -> LDS -> ds_read_b128 fragments -> MFMA.  A wave loads 8 rows x 8 chunks with
+// lanes 0..7 on 8 different rows of one chunk column: each 8-lane ds_write_b128 group then covers 8 distinct 16-byte
+// bank slots (the row-major lane order made every LDS write 8-way conflicted and the kernel LDS-bound).
 // LDS image: each (16 rows x 4 chunks) block is stored [chunk][row][16 B], so lane l of a wave reads bytes
 // [16 l, 16 l + 16) of the block: linear, conflict-free for ds_read_b128 (MI355X_MICROARCH.md §LDS).
 // One LDS stage + register prefetch: the next tile's global loads fly during the MFMAs; 32 KiB of LDS per 128x128
 // workgroup keeps 4 workgroups resident per CU.
 #include "cv_device.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -40,122 +43,10 @@ __device__ __forceinline__ void store_act4(void* base, int64_t idx, float a, flo
   }
 }
 
-template <int DT, int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_kernel(const cv_gemm_params p) {
+template <int DT, int MT, int NT>
+__device__ __forceinline__ void gemm_epilogue(const cv_gemm_params& p, f32x4_t (&acc)[MT][NT], int m0, int n0, int wave_m, int wave_n,
+                                              int lane, int z, int z0, int z1) {
   constexpr int ES = ElemSize<DT>::value;
-  constexpr int CH = 16 / ES;    // elements per 16-byte chunk
-  constexpr int BK = 128 / ES;   // elements per K tile
-  constexpr int MT = BM / 32, NT = BN / 32;
-  constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;
-  constexpr int STAGE = (BM + BN) * 128;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = tid >> 6;
-  const int wave_m = wid >> 1, wave_n = wid & 1;
-
-  const int mtiles = (p.M + BM - 1) / BM;
-  const int tile_m = blockIdx.x % mtiles, tile_n = blockIdx.x / mtiles;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int z = blockIdx.z;
-  const int z1 = z / p.batch_inner, z0 = z - z1 * p.batch_inner;
-
-  const char* Ab = (const char*)p.A + (z0 * p.a_bs0 + z1 * p.a_bs1) * ES;
-  const char* Wb = (const char*)p.W + (z0 * p.w_bs0 + z1 * p.w_bs1) * ES;
-
-  const int nk = (p.K + BK - 1) / BK;
-  const bool conv = p.cin != p.K;
-
-  uint4 ra[A_CH], rb[B_CH];
-  uint32_t amask = 0, bmask = 0;  // validity bits of the prefetched chunks; applied when the tile is written to LDS
-
-  // Tile loads are UNCONDITIONAL (addresses clamped into the operand, out-of-range chunks masked to zero afterwards):
-  // `if (ok) v = load` makes hipcc branch around every load and wait vmcnt(0) each time, which serialises the K loop
-  // on memory latency (cdna_hip_programming.md §5 "Three .s-level traps" (c)).
-  const int a_row_max = p.a_rows - 1, n_max = p.N - 1, k_max = p.K - CH;
-  auto load_tile = [&](int kt) {
-    const int kbase = kt * BK;
-    amask = 0;
-    bmask = 0;
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-      const int c = i * 256 + tid;
-      const int row = c >> 3, kc = c & 7;
-      const int m = m0 + row;
-      const int k = kbase + kc * CH;
-      const int kcl = min(k, k_max);
-      int tap = 0, ci = kcl;
-      if (conv) { tap = kcl / p.cin; ci = kcl - tap * p.cin; }
-      const int arow = m * p.a_row_stride + p.tap_base + tap * p.tap_step;
-      const bool ok = (m < p.M) && (k < p.K) && (arow >= 0) && (arow <= a_row_max);
-      const int arc = min(max(arow, 0), a_row_max);
-      ra[i] = *(const uint4*)(Ab + ((int64_t)arc * p.lda + ci) * ES);
-      amask |= (ok ? 1u : 0u) << i;
-    }
-#pragma unroll
-    for (int i = 0; i < B_CH; ++i) {
-      const int c = i * 256 + tid;
-      const int row = c >> 3, kc = c & 7;
-      const int n = n0 + row;
-      const int k = kbase + kc * CH;
-      const bool ok = (n < p.N) && (k < p.K);
-      rb[i] = *(const uint4*)(Wb + ((int64_t)min(n, n_max) * p.ldw + min(k, k_max)) * ES);
-      bmask |= (ok ? 1u : 0u) << i;
-    }
-  };
-  auto store_tile = [&](int s) {
-    char* sa = smem + s * STAGE;
-    char* sb = sa + BM * 128;
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-      const int c = i * 256 + tid;
-      const uint32_t mk = ((amask >> i) & 1u) ? 0xFFFFFFFFu : 0u;
-      *(uint4*)(sa + lds_chunk_off(c >> 3, c & 7)) = make_uint4(ra[i].x & mk, ra[i].y & mk, ra[i].z & mk, ra[i].w & mk);
-    }
-#pragma unroll
-    for (int i = 0; i < B_CH; ++i) {
-      const int c = i * 256 + tid;
-      const uint32_t mk = ((bmask >> i) & 1u) ? 0xFFFFFFFFu : 0u;
-      *(uint4*)(sb + lds_chunk_off(c >> 3, c & 7)) = make_uint4(rb[i].x & mk, rb[i].y & mk, rb[i].z & mk, rb[i].w & mk);
-    }
-  };
-
-  f32x4_t acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  // single LDS stage (32 KiB at 128x128 -> 4 workgroups per CU) + register prefetch of the next K tile:
-  // occupancy, not a second LDS buffer, hides the global-load latency of these short-K GEMMs
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tile(kt + 1);
-    const char* sa = smem;
-    const char* sb = sa + BM * 128;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      uint4 fa[MT], fb[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) fa[i] = *(const uint4*)(sa + (((wave_m * MT + i) * 2 + ks) << 10) + lane * 16);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) fb[j] = *(const uint4*)(sb + (((wave_n * NT + j) * 2 + ks) << 10) + lane * 16);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = mfma_block<DT>(fb[j], fa[i], acc[i][j]);
-    }
-    if (kt + 1 < nk) {
-      __syncthreads();
-      store_tile(0);
-      __syncthreads();
-    }
-  }
-
   // ------------------------------------------------------------------ epilogue
   // acc[i][j][r]: m = m0 + (wave_m*MT + i)*16 + (lane&15);  n = n0 + (wave_n*NT + j)*16 + 4*(lane>>4) + r
   // All bias / residual / act-param loads are issued UNCONDITIONALLY (clamped addresses, results masked) and hoisted in
@@ -287,6 +178,166 @@ __global__ __launch_bounds__(256) void gemm_kernel(const cv_gemm_params p) {
 }
 
 template <int DT, int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_kernel(const cv_gemm_params p) {
+  constexpr int ES = ElemSize<DT>::value;
+  constexpr int CH = 16 / ES;    // elements per 16-byte chunk
+  constexpr int BK = 128 / ES;   // elements per K tile
+  constexpr int MT = BM / 32, NT = BN / 32;
+  constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;
+  constexpr int STAGE = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wave_m = wid >> 1, wave_n = wid & 1;
+
+  // XCD-aware tile order (speed only, never correctness): blocks are dealt round-robin over the 8 XCDs, each with a
+  // private 4 MiB L2.  Remap (bijective for any grid) so that every XCD walks a CONTIGUOUS range of tile ids, and order
+  // ids so that consecutive tiles share the larger operand's tile: the small operand stays L2-resident, the large one
+  // is fetched from HBM / Infinity Cache once instead of once per tile column.
+  const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
+  int tile_m, tile_n;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    if (p.N <= p.M) { tile_n = id % ntiles; tile_m = id / ntiles; }   // n fastest: the A tile is reused across W tiles
+    else { tile_m = id % mtiles; tile_n = id / mtiles; }              // m fastest: the W tile is reused across A tiles
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int z = blockIdx.z;
+  const int z1 = z / p.batch_inner, z0 = z - z1 * p.batch_inner;
+
+  const char* Ab = (const char*)p.A + (z0 * p.a_bs0 + z1 * p.a_bs1) * ES;
+  const char* Wb = (const char*)p.W + (z0 * p.w_bs0 + z1 * p.w_bs1) * ES;
+
+  const int nk = (p.K + BK - 1) / BK;
+  const bool conv = p.cin != p.K;
+
+  // ---- per-thread loader state, hoisted out of the K loop (the first version recomputed rows, clamps, 64-bit
+  // addresses and LDS offsets per tile: ~200 VALU instructions per 8 MFMAs made the 64x64 tile issue-bound)
+  uint4 ra[A_CH], rb[B_CH];
+  uint32_t amask = 0, bmask = 0;        // validity bits of the prefetched chunks; applied when written to LDS
+  const int k_last = p.K - CH;          // last valid chunk start
+  int a_m_ok[A_CH], a_rowbase[A_CH], a_tap[A_CH], a_ci[A_CH], a_lds[A_CH];
+  const char* a_ptr[A_CH];              // non-conv: fixed row, advances by 128 B per tile
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) {
+    const int c = i * 256 + tid;
+    const int row = ((c >> 6) << 3) + (c & 7), kc = (c >> 3) & 7;  // 8 consecutive lanes = 8 rows of one chunk column
+    const int m = m0 + row;
+    a_lds[i] = lds_chunk_off(row, kc);
+    a_m_ok[i] = m < p.M;
+    a_rowbase[i] = m * p.a_row_stride + p.tap_base;
+    const int k = kc * CH;
+    a_tap[i] = conv ? k / p.cin : 0;
+    a_ci[i] = conv ? k - a_tap[i] * p.cin : k;
+    const int arow = a_rowbase[i];
+    const int arc = min(max(arow, 0), p.a_rows - 1);
+    a_ptr[i] = Ab + ((int64_t)arc * p.lda + k) * ES;
+    if (!conv) a_m_ok[i] = a_m_ok[i] && (arow >= 0) && (arow < p.a_rows);
+  }
+  int b_ok[B_CH], b_lds[B_CH], b_k[B_CH];
+  const char* b_ptr[B_CH];
+#pragma unroll
+  for (int i = 0; i < B_CH; ++i) {
+    const int c = i * 256 + tid;
+    const int row = ((c >> 6) << 3) + (c & 7), kc = (c >> 3) & 7;
+    const int n = n0 + row;
+    b_lds[i] = BM * 128 + lds_chunk_off(row, kc);
+    b_ok[i] = n < p.N;
+    b_k[i] = kc * CH;
+    b_ptr[i] = Wb + ((int64_t)min(n, p.N - 1) * p.ldw + kc * CH) * ES;
+  }
+
+  // Loads are UNCONDITIONAL (clamped addresses; validity applied as a mask when the tile is written to LDS): a load
+  // under a per-element branch makes hipcc wait vmcnt(0) per element and serialises the K loop on memory latency.
+  auto load_tile = [&](int kt) {
+    const int kbase = kt * BK;
+    amask = 0;
+    bmask = 0;
+    if (!conv) {
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        const int k = kbase + a_ci[i];
+        const int back = max(k - k_last, 0);  // elements to step back so a (masked) tail chunk stays inside the row
+        ra[i] = *(const uint4*)(a_ptr[i] + ((int64_t)kbase - back) * ES);
+        amask |= ((a_m_ok[i] && k < p.K) ? 1u : 0u) << i;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        const int k = kbase + (i * 0) + ((((i * 256 + tid) >> 3) & 7) * CH);
+        const int arow = a_rowbase[i] + a_tap[i] * p.tap_step;
+        const bool ok = a_m_ok[i] && (k < p.K) && (arow >= 0) && (arow < p.a_rows);
+        const int arc = min(max(arow, 0), p.a_rows - 1);
+        const int tapc = k < p.K ? a_ci[i] : 0;
+        ra[i] = *(const uint4*)(Ab + ((int64_t)arc * p.lda + tapc) * ES);
+        amask |= (ok ? 1u : 0u) << i;
+        // advance (tap, ci) by one K tile
+        a_ci[i] += BK;
+        while (a_ci[i] >= p.cin) { a_ci[i] -= p.cin; a_tap[i] += 1; }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const int k = kbase + b_k[i];
+      const int back = max(k - k_last, 0);
+      rb[i] = *(const uint4*)(b_ptr[i] + ((int64_t)kbase - back) * ES);
+      bmask |= ((b_ok[i] && k < p.K) ? 1u : 0u) << i;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const uint32_t mk = ((amask >> i) & 1u) ? 0xFFFFFFFFu : 0u;
+      *(uint4*)(smem + a_lds[i]) = make_uint4(ra[i].x & mk, ra[i].y & mk, ra[i].z & mk, ra[i].w & mk);
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const uint32_t mk = ((bmask >> i) & 1u) ? 0xFFFFFFFFu : 0u;
+      *(uint4*)(smem + b_lds[i]) = make_uint4(rb[i].x & mk, rb[i].y & mk, rb[i].z & mk, rb[i].w & mk);
+    }
+  };
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // single LDS stage (occupancy hides latency) + register prefetch of the next K tile
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+  const char* sa = smem;
+  const char* sb = smem + BM * 128;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 fa[MT], fb[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fa[i] = *(const uint4*)(sa + (((wave_m * MT + i) * 2 + ks) << 10) + lane * 16);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb[j] = *(const uint4*)(sb + (((wave_n * NT + j) * 2 + ks) << 10) + lane * 16);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mfma_block<DT>(fb[j], fa[i], acc[i][j]);
+    }
+    if (kt + 1 < nk) {
+      __syncthreads();
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+  gemm_epilogue<DT, MT, NT>(p, acc, m0, n0, wave_m, wave_n, lane, z, z0, z1);
+}
+
+template <int DT, int BM, int BN>
 int launch(const cv_gemm_params& p, hipStream_t st) {
   const int mt = (p.M + BM - 1) / BM, nt = (p.N + BN - 1) / BN;
   dim3 grid(mt * nt, 1, p.batch);
@@ -296,7 +347,167 @@ int launch(const cv_gemm_params& p, hipStream_t st) {
   return CV_OK;
 }
 
-// CV_GEMM_TILE=0|1|2 (128x128 | 128x64 | 64x64) overrides the heuristic: tuning aid only
+// ================================================================================================================
+// gemm_ring_kernel: 128x128 tile, LDS-DMA (global_load_lds, 16 B per lane) into a STAGES-deep ring of 32 KiB stages,
+// counted vmcnt + raw s_barrier so STAGES-1 tiles stay in flight across the MFMA block.  Motivation (measured,
+// DESIGN.md §6): a CU pulls only ~10 B/clk through global loads, so the 64x64 / register-staged kernel is bound by
+// operand traffic (262 MB for a 16000x1024x256 GEMM); a 128x128 tile halves the bytes per flop and the ring keeps the
+// loads in flight at one workgroup per CU.  Same LDS fragment image and epilogue as gemm_kernel.
+// Out-of-range chunks (M/N/K tails, conv padding rows) are fetched from a 16-byte zero word instead of being masked.
+__device__ uint4 g_zero16;
+
+template <int DT, int STAGES>
+__global__ __launch_bounds__(256) void gemm_ring_kernel(const cv_gemm_params p) {
+  constexpr int BM = 128, BN = 128, MT = 4, NT = 4;
+  constexpr int ES = ElemSize<DT>::value;
+  constexpr int CH = 16 / ES;
+  constexpr int BK = 128 / ES;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int NB = 8;  // 1 KiB blocks (16 rows x 4 chunks) per wave per tile: waves 0,1 load A, waves 2,3 load W
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wid >> 1, wave_n = wid & 1;
+  const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
+  int tile_m, tile_n;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    if (p.N <= p.M) { tile_n = id % ntiles; tile_m = id / ntiles; }
+    else { tile_m = id % mtiles; tile_n = id / mtiles; }
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int z = blockIdx.z;
+  const int z1 = z / p.batch_inner, z0 = z - z1 * p.batch_inner;
+  const char* Ab = (const char*)p.A + (z0 * p.a_bs0 + z1 * p.a_bs1) * ES;
+  const char* Wb = (const char*)p.W + (z0 * p.w_bs0 + z1 * p.w_bs1) * ES;
+  const int nk = (p.K + BK - 1) / BK;
+  const bool conv = p.cin != p.K;
+  const bool load_a = wid < 2;
+  const char* zero = (const char*)&g_zero16;
+
+  // block j of this wave: global block id gb = (wid & 1) * 8 + j -> row tile rt = gb >> 1, k half ks = gb & 1
+  const int lr = lane & 15, lgq = lane >> 4;
+  int rowbase[NB / 2];      // A: conv row base per row tile;  (unused for W)
+  bool rok[NB / 2];         // row (m or n) in range
+  const char* rptr[NB / 2]; // non-conv A / W: pointer to (row, chunk lgq) of k half 0
+#pragma unroll
+  for (int t = 0; t < NB / 2; ++t) {
+    const int rt = (wid & 1) * 4 + t;
+    const int row = rt * 16 + lr;
+    if (load_a) {
+      const int m = m0 + row;
+      rowbase[t] = m * p.a_row_stride + p.tap_base;
+      rok[t] = m < p.M;
+      const int arow = rowbase[t];
+      if (!conv) rok[t] = rok[t] && arow >= 0 && arow < p.a_rows;
+      rptr[t] = Ab + ((int64_t)min(max(arow, 0), p.a_rows - 1) * p.lda + lgq * CH) * ES;
+    } else {
+      const int n = n0 + row;
+      rowbase[t] = 0;
+      rok[t] = n < p.N;
+      rptr[t] = Wb + ((int64_t)min(n, p.N - 1) * p.ldw + lgq * CH) * ES;
+    }
+  }
+  // conv: (tap, ci) of this lane's chunk for k half 0 / 1, advanced tile by tile
+  int ctap[2], cci[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int k = (ks * 4 + lgq) * CH;
+    ctap[ks] = conv ? k / p.cin : 0;
+    cci[ks] = conv ? k - ctap[ks] * p.cin : k;
+  }
+
+  auto issue = [&](int kt, int stage) {
+    char* sbase = smem + stage * STAGE + (load_a ? 0 : BM * 128) + (wid & 1) * (NB * 1024);
+    const int kbase = kt * BK;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int t = j >> 1, ks = j & 1;
+      const int k = kbase + (ks * 4 + lgq) * CH;
+      const char* src;
+      if (load_a && conv) {
+        const int arow = rowbase[t] + ctap[ks] * p.tap_step;
+        const bool ok = rok[t] && k < p.K && arow >= 0 && arow < p.a_rows;
+        src = ok ? Ab + ((int64_t)arow * p.lda + cci[ks]) * ES : zero;
+      } else {
+        const bool ok = rok[t] && k < p.K;
+        src = ok ? rptr[t] + ((int64_t)kbase + ks * 4 * CH) * ES : zero;
+      }
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(sbase + j * 1024), 16, 0, 0);
+    }
+    if (conv) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        cci[ks] += BK;
+        while (cci[ks] >= p.cin) { cci[ks] -= p.cin; ctap[ks] += 1; }
+      }
+    }
+  };
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: STAGES-1 tiles in flight
+#pragma unroll
+  for (int s2 = 0; s2 < STAGES - 1; ++s2)
+    if (s2 < nk) issue(s2, s2);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int stage = kt % STAGES;
+    if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+    // tiles still allowed in flight after this wait: min(STAGES-1, nk-1-kt), 8 loads each
+    const int ahead = min(STAGES - 1, nk - 1 - kt);
+    if (ahead >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (ahead == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* sa = smem + stage * STAGE;
+    const char* sb = sa + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 fa[MT], fb[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fa[i] = *(const uint4*)(sa + (((wave_m * MT + i) * 2 + ks) << 10) + lane * 16);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb[j] = *(const uint4*)(sb + (((wave_n * NT + j) * 2 + ks) << 10) + lane * 16);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mfma_block<DT>(fb[j], fa[i], acc[i][j]);
+    }
+    // WAR: this stage is refilled by the issue() of the next iteration
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  gemm_epilogue<DT, MT, NT>(p, acc, m0, n0, wave_m, wave_n, lane, z, z0, z1);
+}
+
+template <int DT>
+int launch_ring(const cv_gemm_params& p, hipStream_t st) {
+  const int mt = (p.M + 127) / 128, nt = (p.N + 127) / 128;
+  dim3 grid(mt * nt, 1, p.batch);
+  constexpr int STAGES = 3;
+  const size_t lds = (size_t)STAGES * 256 * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_ring_kernel<DT, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_ring_kernel<DT, STAGES>), grid, dim3(256), lds, st, p);
+  CV_CHECK_LAUNCH();
+  return CV_OK;
+}
+
+// CV_GEMM_TILE=0|1|2|3 (128x128 | 128x64 | 64x64 | 128x128 LDS-DMA ring) overrides the heuristic: tuning aid only
 static int g_tile_override = -2;
 
 template <int DT>
@@ -316,7 +527,8 @@ int dispatch(const cv_gemm_params& p, hipStream_t st) {
     if (p.K > 512 && t12864 >= 768) tile = 1;
     else tile = 2;
   }
-  if (swiglu && tile == 0) tile = 1;
+  if (swiglu && (tile == 0 || tile == 3)) tile = 1;
+  if (tile == 3) return launch_ring<DT>(p, st);
   if (tile == 0) return launch<DT, 128, 128>(p, st);
   if (tile == 1) return launch<DT, 128, 64>(p, st);
   return launch<DT, 64, 64>(p, st);

@@ -4,13 +4,13 @@
 
 namespace {
 
-template <int ODT>
+// MAXV = float4 per lane: 1 / 2 / 4 / 8 for dim <= 256 / 512 / 1024 / 2048 (no masked-out load instructions)
+template <int ODT, int MAXV>
 __global__ __launch_bounds__(256) void norm_kernel(const cv_norm_params p) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.rows) return;
   const float* x = p.x + (int64_t)row * p.ldx;
-  constexpr int MAXV = 8;  // float4 per lane -> dim <= 64*4*8 = 2048
   float4 v[MAXV];
   const int nv = p.dim >> 2;
   float s = 0.f;
@@ -84,12 +84,20 @@ extern "C" int cv_layernorm(const cv_norm_params* pp, void* stream) {
   if (p.rows_per_group <= 0) p.rows_per_group = p.rows;
   dim3 grid((p.rows + 3) / 4);
   hipStream_t st = (hipStream_t)stream;
+#define NORM_LAUNCH(ODT_)                                                                                    \
+  do {                                                                                                       \
+    if (p.dim <= 256) hipLaunchKernelGGL((norm_kernel<ODT_, 1>), grid, dim3(256), 0, st, p);                  \
+    else if (p.dim <= 512) hipLaunchKernelGGL((norm_kernel<ODT_, 2>), grid, dim3(256), 0, st, p);             \
+    else if (p.dim <= 1024) hipLaunchKernelGGL((norm_kernel<ODT_, 4>), grid, dim3(256), 0, st, p);            \
+    else hipLaunchKernelGGL((norm_kernel<ODT_, 8>), grid, dim3(256), 0, st, p);                               \
+  } while (0)
   switch (p.out_dtype) {
-    case CV_F32: hipLaunchKernelGGL(norm_kernel<CV_F32>, grid, dim3(256), 0, st, p); break;
-    case CV_BF16: hipLaunchKernelGGL(norm_kernel<CV_BF16>, grid, dim3(256), 0, st, p); break;
-    case CV_F16: hipLaunchKernelGGL(norm_kernel<CV_F16>, grid, dim3(256), 0, st, p); break;
+    case CV_F32: NORM_LAUNCH(CV_F32); break;
+    case CV_BF16: NORM_LAUNCH(CV_BF16); break;
+    case CV_F16: NORM_LAUNCH(CV_F16); break;
     default: return CV_ERR_ARG;
   }
+#undef NORM_LAUNCH
   CV_CHECK_LAUNCH();
   return CV_OK;
 }

@@ -46,7 +46,9 @@ class CosyVoice2Model:
         self.source_cache_len = int(self.mel_cache_len * 480)
         self.speech_window = np.hamming(2 * self.source_cache_len)
         self.stream_scale_factor = 1
-        self.llm_context = torch.cuda.stream(torch.cuda.Stream(self.device))
+        # high-priority side stream: the decode loop is a chain of short dependent kernels that must not queue behind the
+        # flow GEMMs of the previous batch when both streams are busy (tts_batches)
+        self.llm_context = torch.cuda.stream(torch.cuda.Stream(self.device, priority=-1))
         self.lock = threading.Lock()
         self.tts_speech_token_dict = {}
         self.llm_end_dict = {}
@@ -164,3 +166,32 @@ class CosyVoice2Model:
         mel = self.flow.inference_batch(tok, flow_prompt_speech_tokens, prompt_speech_feats, flow_embeddings)
         wav, _ = self.hift.inference(speech_feat=mel.contiguous(), cache_source=torch.zeros(1, 1, 0))
         return wav.cpu() if to_host else wav
+
+    @torch.no_grad()
+    def tts_batches(self, batches, to_host: bool = True):
+        """Generator over a list of utterance batches (each a dict of tts_batch's arguments), software-pipelined over two
+        streams the way the reference overlaps its LLM thread with flow/HiFT (cli/model.py:62,119,189): the LLM decode of
+        batch i+1 (latency-bound graph replays, LLM side stream) runs while flow + HiFT of batch i (throughput-bound GEMMs,
+        caller's stream) execute.  A batch may carry ``on_start`` (callable, e.g. the RCCL conditioning broadcast)."""
+        llm_stream = self.llm_context.stream if hasattr(self.llm_context, "stream") else torch.cuda.Stream()
+        pending = None
+        for b in list(batches) + [None]:
+            toks = None
+            if b is not None:
+                with torch.cuda.stream(llm_stream):
+                    if b.get("on_start") is not None:
+                        b["on_start"]()  # e.g. the conditioning broadcast: issued on the LLM stream, never behind flow work
+                    ready = torch.cuda.Event()
+                    ready.record(llm_stream)
+                    toks = self.llm.generate_batch(b["texts"], b["prompt_texts"], b["llm_prompt_speech_tokens"], forced=b.get("forced"))
+            if pending is not None:
+                yield pending.cpu() if to_host else pending.clone()
+                pending = None
+            if toks is not None:
+                n = len(toks[0])
+                assert all(len(t) == n for t in toks), "tts_batches needs equal generated lengths per batch"
+                torch.cuda.current_stream().wait_event(ready)  # conditioning of this batch is in place
+                tok = torch.tensor(toks, dtype=torch.int32, device=self.device)
+                mel = self.flow.inference_batch(tok, b["flow_prompt_speech_tokens"], b["prompt_speech_feats"], b["flow_embeddings"])
+                wav, _ = self.hift.inference(speech_feat=mel.contiguous(), cache_source=torch.zeros(1, 1, 0))
+                pending = wav
