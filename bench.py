@@ -205,9 +205,10 @@ def main():
 
 
 def measure_roofline(llm, lc):
-    """Dominant kernel = the decode step's gate/up skinny GEMM (skinny_kernel<bf16,2>): streams the layer's
-    2*4864*896 bf16 gate/up weights once per launch for all 8 sequences.  Algorithmic bytes per launch = packed
-    weight bytes + activations in (16x896 bf16) + SwiGLU out (8x4864 bf16) — DESIGN.md "Roofline"."""
+    """Roofline kernel = the decode step's gate/up skinny GEMM (exactly one shape in this workload, so the rocprof
+    per-kernel average and this live measurement describe the same launches): it streams the layer's 2*4864*896 bf16
+    gate/up weights once per launch for all 8 sequences — the largest weight stream of the HBM-bound decode stage (47 % of
+    kernel time).  Algorithmic bytes per launch: DESIGN.md §6."""
     from cosyvoice_amd import ops
     st, lay = llm.st, llm.layers
     H, I = lc.hidden_size, lc.intermediate_size
@@ -216,19 +217,30 @@ def measure_roofline(llm, lc):
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     # cycle through all 24 layers' weights (417 MB > 256 MB Infinity Cache) so every launch streams from HBM
+    def launch(l):
+        ops.skinny_gemm(st["xn"], l["p_gu"], B, 2 * I, H, mode=2, out_act=st["h"], ldoa=I,
+                        norm=dict(x=st["x2"], gamma=l["g_post"], eps=lc.rms_eps))
+
     for l in lay:
-        ops.skinny_gemm(st["xn"], l["p_gu"], B, 2 * I, H, mode=2, out_act=st["h"], ldoa=I)
+        launch(l)
     ev0.record()
     for _ in range(n_iter):
         for l in lay:
-            ops.skinny_gemm(st["xn"], l["p_gu"], B, 2 * I, H, mode=2, out_act=st["h"], ldoa=I)
+            launch(l)
     ev1.record()
     torch.cuda.synchronize()
     dur = ev0.elapsed_time(ev1) * 1e-3 / (n_iter * len(lay))
-    alg = 2 * I * H * 2 + 16 * H * 2 + B * I * 2
-    return {"bound": "hbm", "kernel": "skinny_kernel<bf16,2> (decode gate/up + SwiGLU)", "achieved": round(alg / dur / 1e9, 1),
-            "peak": 8000.0, "unit": "GB/s", "frac": round(alg / dur / 8e12, 4), "traffic": None,
-            "bytes_per_launch": alg, "avg_launch_us": round(dur * 1e6, 3)}
+    alg = 2 * I * H * 2 + B * H * 4 + H * 4 + B * I * 2   # packed bf16 weights + fp32 residual rows + gamma + bf16 SwiGLU out
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_roofline_pmc.json")
+    if os.path.exists(pmc):  # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/roofline_pmc.py)
+        try:
+            traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+    return {"bound": "hbm", "kernel": "skinny_kernel<bf16,TPW=2,norm,TPR=32> (decode gate/up + RMSNorm prologue + SwiGLU)",
+            "achieved": round(alg / dur / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg / dur / 8e12, 4),
+            "traffic": traffic, "bytes_per_launch": alg, "avg_launch_us": round(dur * 1e6, 3)}
 
 
 if __name__ == "__main__":

@@ -1,0 +1,16 @@
+"""Runs ONLY the roofline kernel of bench.py (decode gate/up skinny GEMM, B=8, all 24 layers' packed weights, 5 sweeps)
+so that rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes give its HBM traffic per launch."""
+import sys, torch
+sys.path.insert(0, '.')
+from cosyvoice_amd import ops
+H, I, B, L = 896, 4864, 8, 24
+dev = 'cuda'
+torch.manual_seed(0)
+xn = torch.zeros(16, H, device=dev, dtype=torch.bfloat16); xn[:B] = torch.randn(B, H, device=dev).to(torch.bfloat16)
+x = torch.randn(16, H, device=dev); gam = torch.ones(H, device=dev)
+h = torch.zeros(16, I, device=dev, dtype=torch.bfloat16)
+packs = [ops.pack_skinny((torch.randn(2 * I, H, device=dev) / H ** 0.5).to(torch.bfloat16), interleave=True) for _ in range(L)]
+for _ in range(5):
+    for p in packs:
+        ops.skinny_gemm(xn, p, B, 2 * I, H, mode=2, out_act=h, ldoa=I, norm=dict(x=x, gamma=gam, eps=1e-6))
+torch.cuda.synchronize()
