@@ -233,6 +233,17 @@ int cv_sample_ras(const cv_sample_params* p, void* stream);
 int cv_sizeof_skinny_params(void);
 int cv_sizeof_sample_params(void);
 
+/* ------------------------------------------------------------------------------------------
+ * BigVGAN fused anti-aliased activation — the reference's only native kernel
+ * (cosyvoice/BigVGAN/alias_free_activation/cuda/anti_alias_activation_cuda.cu:44-181, binding
+ * anti_alias_activation.cpp:19-23, wrapper cuda/activation1d.py:13-76; semantics = torch path
+ * alias_free_activation/torch/{act,resample,filter}.py): per channel, replicate-pad(5) -> 2x upsample with the 12-tap
+ * kaiser-sinc filter (x2 gain) -> SnakeBeta x + sin^2(x e^a)/(e^b + 1e-9) -> replicate-pad(5,6) -> 12-tap low-pass,
+ * stride 2.  x, y [B][C][T] of `dtype` (f32 / bf16 / f16), filters and log-scale alpha/beta fp32, fp32 accumulation.
+ * ------------------------------------------------------------------------------------------ */
+int cv_anti_alias_act(const void* x, void* y, int32_t dtype, int32_t B, int32_t C, int32_t T, const float* up_filter,
+                      const float* down_filter, const float* alpha_log, const float* beta_log, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -339,17 +339,38 @@ def golden_llm():
     save("sampler", scores=scores, candidates=np.stack(cand))
 
 
+# ----------------------------------------------------------------------------- BigVGAN activation
+def golden_bigvgan_act():
+    """Reference torch path of the fused kernel: alias_free_activation/torch/act.py Activation1d + nnet SnakeBeta."""
+    from cosyvoice.BigVGAN.alias_free_activation.torch.act import Activation1d
+    from cosyvoice.BigVGAN.nnet.activations import SnakeBeta
+    g = torch.Generator().manual_seed(41)
+    C, T = 6, 301
+    act = SnakeBeta(C, alpha_logscale=True)
+    with torch.no_grad():
+        act.alpha.copy_(torch.randn(C, generator=g) * 0.5)
+        act.beta.copy_(torch.randn(C, generator=g) * 0.5)
+    m = Activation1d(activation=act)
+    x = torch.randn(2, C, T, generator=g) * 1.5
+    with torch.inference_mode():
+        y = m(x)
+    save("bigvgan_act", x=x, alpha_log=act.alpha.detach(), beta_log=act.beta.detach(), y=y,
+         up_filter=m.upsample.filter.reshape(-1), down_filter=m.downsample.lowpass.filter.reshape(-1))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     install_stubs()
-    which = sys.argv[1:] or ["hift", "flow", "llm"]
+    which = sys.argv[1:] or ["hift", "flow", "llm", "bigvgan"]
     if "hift" in which:
         golden_hift()
     if "flow" in which:
         golden_flow()
     if "llm" in which:
         golden_llm()
+    if "bigvgan" in which:
+        golden_bigvgan_act()
 
 
 if __name__ == "__main__":

@@ -105,3 +105,13 @@ def test_ras_repetition_fallback():
     assert ol.ras_sampling(scores, [1, 2, 3], (0.5, 0.999999)) == 7
     # 7 already in the window -> falls back to sampling the full distribution with the second uniform
     assert ol.ras_sampling(scores, [7, 2, 3], (0.5, 0.0)) == 0
+
+
+def test_bigvgan_anti_alias_activation(golden_dir):
+    from oracle import bigvgan as ob
+    from cosyvoice_amd.bigvgan import kaiser_sinc_filter12
+    g = _load(golden_dir, "bigvgan_act")
+    y = ob.anti_alias_activation(g["x"], g["alpha_log"], g["beta_log"])
+    assert (y - g["y"]).abs().max().item() < 1e-5
+    assert (ob.kaiser_sinc_filter1d(0.25, 0.3, 12).reshape(-1) - g["up_filter"]).abs().max().item() < 1e-7
+    assert (kaiser_sinc_filter12() - g["down_filter"]).abs().max().item() < 1e-7  # the product's own filter table
