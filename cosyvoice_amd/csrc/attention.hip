@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int KT_BYTES = 8192;        // K tile: 4 key-tiles x 2 k-steps x 1 KiB fragment blocks
+constexpr int KT_BYTES = 8192;        // K tile: 64 keys x 128 B, row-major with XOR-swizzled 16-byte chunk slots
 constexpr int VT_PITCH = 144;         // bytes per d-row of the V^T tile (128 data + 16 pad)
 constexpr int VT_BYTES = 64 * VT_PITCH;
 constexpr int STAGE_BYTES = KT_BYTES + VT_BYTES;
@@ -23,6 +23,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const cv_attn_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lq = lane & 15, lg = lane >> 4;
+  const int kfrag0 = (lq << 7) + ((lg ^ ((lq >> 1) & 7)) << 4), kfrag1 = (lq << 7) + (((4 + lg) ^ ((lq >> 1) & 7)) << 4);
   const int b = blockIdx.z, h = blockIdx.y;
   const int hk = h / (p.H / p.Hkv);
   const int q_wg = blockIdx.x * 128;
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const cv_attn_params p) {
     for (int i = 0; i < 2; ++i) {
       const int c = i * 256 + tid;
       const int r = c >> 3, dc = c & 7;
-      const int kr = ((c >> 6) << 3) + (c & 7), kdc = (c >> 3) & 7;  // K: lanes 0..7 on 8 keys of one d chunk (LDS write banks)
+      const int kr = r, kdc = dc;  // K: 8 consecutive lanes = one 128-byte key row
       rk[i] = *(const uint4*)(Kp + (int64_t)min(j0 + kr, key_max) * p.ldk + kdc * 8);
       rv[i] = *(const uint4*)(Vt + (int64_t)r * p.vt_ld + min(j0 + dc * 8, vchunk_max));  // r = d row, dc = key chunk
     }
@@ -79,9 +80,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const cv_attn_params p) {
     for (int i = 0; i < 2; ++i) {
       const int c = i * 256 + tid;
       const int r = c >> 3, dc = c & 7;
-      const int kr = ((c >> 6) << 3) + (c & 7), kdc = (c >> 3) & 7;
+      const int kr = r, kdc = dc;
       const uint32_t km = (tile_j0 + kr < klen) ? 0xFFFFFFFFu : 0u;
-      *(uint4*)(sk + (((kr >> 4) * 2 + (kdc >> 2)) << 10) + ((kdc & 3) << 8) + ((kr & 15) << 4)) =
+      *(uint4*)(sk + (kr << 7) + ((kdc ^ ((kr >> 1) & 7)) << 4)) =  // row-major, XOR-swizzled chunk slot (see gemm.hip)
           make_uint4(rk[i].x & km, rk[i].y & km, rk[i].z & km, rk[i].w & km);
       // zero every key >= klen of the V^T chunk (0 * garbage must not become NaN)
       const int nvalid = klen - (tile_j0 + dc * 8);
@@ -121,8 +122,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const cv_attn_params p) {
     f32x4_t sacc[4][2];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      const uint4 k0 = *(const uint4*)(sk + ((kt * 2 + 0) << 10) + lane * 16);
-      const uint4 k1 = *(const uint4*)(sk + ((kt * 2 + 1) << 10) + lane * 16);
+      const uint4 k0 = *(const uint4*)(sk + (kt << 11) + kfrag0);
+      const uint4 k1 = *(const uint4*)(sk + (kt << 11) + kfrag1);
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
         f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};

@@ -18,8 +18,12 @@ namespace {
 
 template <int DT> struct ElemSize { static constexpr int value = (DT == CV_F32) ? 4 : 2; };
 
+// LDS tile image: plain row-major, 128 bytes (8 x 16-byte chunks) per row, chunk position XOR-swizzled by (row>>1)&7.
+//  * global loads stay row-contiguous (8 lanes = one full 128-byte line; the transposed lane order measured 1.6x slower),
+//  * the 8-lane ds_write_b128 groups write 8 distinct 16-byte slots of one row: conflict-free,
+//  * the MFMA fragment read (lane = row l&15, chunk ks*4 + (l>>4)) hits 16 distinct slots per ds_read_b128 lane group.
 __device__ __forceinline__ int lds_chunk_off(int row, int kc) {
-  return (((row >> 4) * 2 + (kc >> 2)) << 10) + ((kc & 3) << 8) + ((row & 15) << 4);
+  return (row << 7) + ((kc ^ ((row >> 1) & 7)) << 4);
 }
 
 template <int DT>
@@ -191,6 +195,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const cv_gemm_params p) {
   const int lane = tid & 63;
   const int wid = tid >> 6;
   const int wave_m = wid >> 1, wave_n = wid & 1;
+  // byte offset of this lane's fragment chunk inside a 16-row (2 KiB) block, for k half 0 / 1
+  const int frag_off[2] = {((lane & 15) << 7) + ((((lane >> 4)) ^ (((lane & 15) >> 1) & 7)) << 4),
+                           ((lane & 15) << 7) + (((4 + (lane >> 4)) ^ (((lane & 15) >> 1) & 7)) << 4)};
 
   // XCD-aware tile order (speed only, never correctness): blocks are dealt round-robin over the 8 XCDs, each with a
   // private 4 MiB L2.  Remap (bijective for any grid) so that every XCD walks a CONTIGUOUS range of tile ids, and order
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const cv_gemm_params p) {
 #pragma unroll
   for (int i = 0; i < A_CH; ++i) {
     const int c = i * 256 + tid;
-    const int row = ((c >> 6) << 3) + (c & 7), kc = (c >> 3) & 7;  // 8 consecutive lanes = 8 rows of one chunk column
+    const int row = c >> 3, kc = c & 7;  // 8 consecutive lanes = one 128-byte line of a row
     const int m = m0 + row;
     a_lds[i] = lds_chunk_off(row, kc);
     a_m_ok[i] = m < p.M;
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const cv_gemm_params p) {
 #pragma unroll
   for (int i = 0; i < B_CH; ++i) {
     const int c = i * 256 + tid;
-    const int row = ((c >> 6) << 3) + (c & 7), kc = (c >> 3) & 7;
+    const int row = c >> 3, kc = c & 7;
     const int n = n0 + row;
     b_lds[i] = BM * 128 + lds_chunk_off(row, kc);
     b_ok[i] = n < p.N;
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const cv_gemm_params p) {
     } else {
 #pragma unroll
       for (int i = 0; i < A_CH; ++i) {
-        const int k = kbase + (i * 0) + ((((i * 256 + tid) >> 3) & 7) * CH);
+        const int k = kbase + ((i * 256 + tid) & 7) * CH;
         const int arow = a_rowbase[i] + a_tap[i] * p.tap_step;
         const bool ok = a_m_ok[i] && (k < p.K) && (arow >= 0) && (arow < p.a_rows);
         const int arc = min(max(arow, 0), p.a_rows - 1);
@@ -319,9 +326,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const cv_gemm_params p) {
     for (int ks = 0; ks < 2; ++ks) {
       uint4 fa[MT], fb[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) fa[i] = *(const uint4*)(sa + (((wave_m * MT + i) * 2 + ks) << 10) + lane * 16);
+      for (int i = 0; i < MT; ++i) fa[i] = *(const uint4*)(sa + ((wave_m * MT + i) << 11) + frag_off[ks]);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) fb[j] = *(const uint4*)(sb + (((wave_n * NT + j) * 2 + ks) << 10) + lane * 16);
+      for (int j = 0; j < NT; ++j) fb[j] = *(const uint4*)(sb + ((wave_n * NT + j) << 11) + frag_off[ks]);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -371,6 +378,9 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(const cv_gemm_params p) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_m = wid >> 1, wave_n = wid & 1;
+  // byte offset of this lane's fragment chunk inside a 16-row (2 KiB) block, for k half 0 / 1
+  const int frag_off[2] = {((lane & 15) << 7) + ((((lane >> 4)) ^ (((lane & 15) >> 1) & 7)) << 4),
+                           ((lane & 15) << 7) + (((4 + (lane >> 4)) ^ (((lane & 15) >> 1) & 7)) << 4)};
   const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
   int tile_m, tile_n;
   {
@@ -390,36 +400,32 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(const cv_gemm_params p) 
   const bool load_a = wid < 2;
   const char* zero = (const char*)&g_zero16;
 
-  // block j of this wave: global block id gb = (wid & 1) * 8 + j -> row tile rt = gb >> 1, k half ks = gb & 1
-  const int lr = lane & 15, lgq = lane >> 4;
-  int rowbase[NB / 2];      // A: conv row base per row tile;  (unused for W)
-  bool rok[NB / 2];         // row (m or n) in range
-  const char* rptr[NB / 2]; // non-conv A / W: pointer to (row, chunk lgq) of k half 0
+  // LDS-DMA writes 1 KiB per wave instruction at base + lane*16 = 8 consecutive rows x 8 chunk slots of the row-major
+  // image; the XOR swizzle therefore goes on the SOURCE: lane (row lr8 = lane>>3, slot = lane&7) fetches chunk
+  // slot ^ ((row>>1)&7) of its row (cdna guide rule 21: linear dest + swizzled source + swizzled read).
+  // block j (of 8) of this wave covers rows (wid&1)*64 + j*8 .. +7 of the A (waves 0,1) or W (waves 2,3) tile.
+  const int lr8 = lane >> 3, slot = lane & 7;
+  int rowbase[NB];
+  bool rok[NB];
+  const char* rptr[NB];  // non-conv A / W: pointer to (row, chunk) at k = 0
+  int kch[NB];           // source chunk index (0..7) of this lane in block j
 #pragma unroll
-  for (int t = 0; t < NB / 2; ++t) {
-    const int rt = (wid & 1) * 4 + t;
-    const int row = rt * 16 + lr;
+  for (int j = 0; j < NB; ++j) {
+    const int row = (wid & 1) * 64 + j * 8 + lr8;
+    kch[j] = slot ^ ((row >> 1) & 7);
     if (load_a) {
       const int m = m0 + row;
-      rowbase[t] = m * p.a_row_stride + p.tap_base;
-      rok[t] = m < p.M;
-      const int arow = rowbase[t];
-      if (!conv) rok[t] = rok[t] && arow >= 0 && arow < p.a_rows;
-      rptr[t] = Ab + ((int64_t)min(max(arow, 0), p.a_rows - 1) * p.lda + lgq * CH) * ES;
+      rowbase[j] = m * p.a_row_stride + p.tap_base;
+      rok[j] = m < p.M;
+      const int arow = rowbase[j];
+      if (!conv) rok[j] = rok[j] && arow >= 0 && arow < p.a_rows;
+      rptr[j] = Ab + ((int64_t)min(max(arow, 0), p.a_rows - 1) * p.lda + kch[j] * CH) * ES;
     } else {
       const int n = n0 + row;
-      rowbase[t] = 0;
-      rok[t] = n < p.N;
-      rptr[t] = Wb + ((int64_t)min(n, p.N - 1) * p.ldw + lgq * CH) * ES;
+      rowbase[j] = 0;
+      rok[j] = n < p.N;
+      rptr[j] = Wb + ((int64_t)min(n, p.N - 1) * p.ldw + kch[j] * CH) * ES;
     }
-  }
-  // conv: (tap, ci) of this lane's chunk for k half 0 / 1, advanced tile by tile
-  int ctap[2], cci[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const int k = (ks * 4 + lgq) * CH;
-    ctap[ks] = conv ? k / p.cin : 0;
-    cci[ks] = conv ? k - ctap[ks] * p.cin : k;
   }
 
   auto issue = [&](int kt, int stage) {
@@ -427,25 +433,18 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(const cv_gemm_params p) 
     const int kbase = kt * BK;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      const int t = j >> 1, ks = j & 1;
-      const int k = kbase + (ks * 4 + lgq) * CH;
+      const int k = kbase + kch[j] * CH;
       const char* src;
       if (load_a && conv) {
-        const int arow = rowbase[t] + ctap[ks] * p.tap_step;
-        const bool ok = rok[t] && k < p.K && arow >= 0 && arow < p.a_rows;
-        src = ok ? Ab + ((int64_t)arow * p.lda + cci[ks]) * ES : zero;
+        const int tap = k / p.cin, ci = k - tap * p.cin;
+        const int arow = rowbase[j] + tap * p.tap_step;
+        const bool ok = rok[j] && k < p.K && arow >= 0 && arow < p.a_rows;
+        src = ok ? Ab + ((int64_t)arow * p.lda + ci) * ES : zero;
       } else {
-        const bool ok = rok[t] && k < p.K;
-        src = ok ? rptr[t] + ((int64_t)kbase + ks * 4 * CH) * ES : zero;
+        const bool ok = rok[j] && k < p.K;
+        src = ok ? rptr[j] + (int64_t)kbase * ES : zero;
       }
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(sbase + j * 1024), 16, 0, 0);
-    }
-    if (conv) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        cci[ks] += BK;
-        while (cci[ks] >= p.cin) { cci[ks] -= p.cin; ctap[ks] += 1; }
-      }
     }
   };
 
@@ -476,9 +475,9 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(const cv_gemm_params p) 
     for (int ks = 0; ks < 2; ++ks) {
       uint4 fa[MT], fb[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) fa[i] = *(const uint4*)(sa + (((wave_m * MT + i) * 2 + ks) << 10) + lane * 16);
+      for (int i = 0; i < MT; ++i) fa[i] = *(const uint4*)(sa + ((wave_m * MT + i) << 11) + frag_off[ks]);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) fb[j] = *(const uint4*)(sb + (((wave_n * NT + j) * 2 + ks) << 10) + lane * 16);
+      for (int j = 0; j < NT; ++j) fb[j] = *(const uint4*)(sb + ((wave_n * NT + j) << 11) + frag_off[ks]);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
