@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--flow-dtype", default="fp16", choices=["fp16", "bf16"])
     args = ap.parse_args()
 
+    torch.set_num_threads(min(16, torch.get_num_threads()))  # CPU share per GPU on the box; keeps 8 ranks from oversubscribing
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -178,6 +179,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- batch-1 latency of the same pipeline (BASELINE metric: "batch 1 and 8"; north_star target RTF < 0.05), rank 0 only
+    b1 = None
+    if rank == 0:
+        one = dict(texts=texts_d[:1], prompt_texts=[make_batch()["prompt_texts"][0]], llm_prompt_speech_tokens=[make_batch()["llm_prompt_speech_tokens"][0]],
+                   flow_prompt_speech_tokens=make_batch()["flow_prompt_speech_tokens"][:1], prompt_speech_feats=make_batch()["prompt_speech_feats"][:1],
+                   flow_embeddings=make_batch()["flow_embeddings"][:1], forced=forced[:1])
+        def run1():
+            return model.tts_batch(one["texts"], one["prompt_texts"], one["llm_prompt_speech_tokens"], one["flow_prompt_speech_tokens"],
+                                   one["prompt_speech_feats"], one["flow_embeddings"], forced=one["forced"], to_host=True)
+        for _ in range(2):
+            run1()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n1 = 3
+        for _ in range(n1):
+            run1()
+        torch.cuda.synchronize()
+        lat = (time.perf_counter() - t1) / n1
+        b1 = {"latency_ms": round(lat * 1e3, 2), "rtf": round(lat / AUDIO_S_PER_UTT, 5), "audio_s_per_s": round(AUDIO_S_PER_UTT / lat, 2)}
+
     # ---- roofline of the dominant kernel, measured live with events on the launch stream
     roof = measure_roofline(llm, lc)
 
@@ -193,7 +214,8 @@ def main():
             "data": "synthetic (key-seeded random weights of the reference architecture, teacher-forced 250 tokens)",
             "config": {"workload": "C4 full LLM->flow->HiFT pipeline, 8 utterances x 10 s per GPU, 10 s prompt "
                                    "(prefill 282, N_g 250, flow T 1000 x 10 CFG Euler steps, HiFT 500 frames)",
-                       "utterances_per_gpu": B, "rtf": round(elapsed / audio_s, 6), "parallelism": f"utterance-parallel x{world}"},
+                       "utterances_per_gpu": B, "rtf": round(elapsed / audio_s, 6), "parallelism": f"utterance-parallel x{world}",
+                       "batch1": b1},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

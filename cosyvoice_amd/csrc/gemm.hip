@@ -181,20 +181,22 @@ __device__ __forceinline__ void gemm_epilogue(const cv_gemm_params& p, f32x4_t (
   }
 }
 
-template <int DT, int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_kernel(const cv_gemm_params p) {
+// WM x WN waves per workgroup (NT_ = 64*WM*WN threads); each wave owns (BM/WM) x (BN/WN) of the tile.
+template <int DT, int BM, int BN, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const cv_gemm_params p) {
+  constexpr int NTHR = 64 * WM * WN;
   constexpr int ES = ElemSize<DT>::value;
   constexpr int CH = 16 / ES;    // elements per 16-byte chunk
   constexpr int BK = 128 / ES;   // elements per K tile
-  constexpr int MT = BM / 32, NT = BN / 32;
-  constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;
+  constexpr int MT = BM / (16 * WM), NT = BN / (16 * WN);
+  constexpr int A_CH = BM * 8 / NTHR, B_CH = BN * 8 / NTHR;
   constexpr int STAGE = (BM + BN) * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = tid >> 6;
-  const int wave_m = wid >> 1, wave_n = wid & 1;
+  const int wave_m = wid / WN, wave_n = wid % WN;
   // byte offset of this lane's fragment chunk inside a 16-row (2 KiB) block, for k half 0 / 1
   const int frag_off[2] = {((lane & 15) << 7) + ((((lane >> 4)) ^ (((lane & 15) >> 1) & 7)) << 4),
                            ((lane & 15) << 7) + (((4 + (lane >> 4)) ^ (((lane & 15) >> 1) & 7)) << 4)};
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const cv_gemm_params p) {
   const char* a_ptr[A_CH];              // non-conv: fixed row, advances by 128 B per tile
 #pragma unroll
   for (int i = 0; i < A_CH; ++i) {
-    const int c = i * 256 + tid;
+    const int c = i * NTHR + tid;
     const int row = c >> 3, kc = c & 7;  // 8 consecutive lanes = one 128-byte line of a row
     const int m = m0 + row;
     a_lds[i] = lds_chunk_off(row, kc);
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const cv_gemm_params p) {
   const char* b_ptr[B_CH];
 #pragma unroll
   for (int i = 0; i < B_CH; ++i) {
-    const int c = i * 256 + tid;
+    const int c = i * NTHR + tid;
     const int row = c >> 3, kc = c & 7;
     const int n = n0 + row;
     b_lds[i] = BM * 128 + lds_chunk_off(row, kc);
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const cv_gemm_params p) {
     } else {
 #pragma unroll
       for (int i = 0; i < A_CH; ++i) {
-        const int k = kbase + ((i * 256 + tid) & 7) * CH;
+        const int k = kbase + ((i * NTHR + tid) & 7) * CH;
         const int arow = a_rowbase[i] + a_tap[i] * p.tap_step;
         const bool ok = a_m_ok[i] && (k < p.K) && (arow >= 0) && (arow < p.a_rows);
         const int arc = min(max(arow, 0), p.a_rows - 1);
@@ -344,12 +346,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const cv_gemm_params p) {
   gemm_epilogue<DT, MT, NT>(p, acc, m0, n0, wave_m, wave_n, lane, z, z0, z1);
 }
 
-template <int DT, int BM, int BN>
+template <int DT, int BM, int BN, int WM = 2, int WN = 2>
 int launch(const cv_gemm_params& p, hipStream_t st) {
   const int mt = (p.M + BM - 1) / BM, nt = (p.N + BN - 1) / BN;
   dim3 grid(mt * nt, 1, p.batch);
   const size_t lds = (BM + BN) * 128;
-  hipLaunchKernelGGL((gemm_kernel<DT, BM, BN>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((gemm_kernel<DT, BM, BN, WM, WN>), grid, dim3(64 * WM * WN), lds, st, p);
   CV_CHECK_LAUNCH();
   return CV_OK;
 }
@@ -528,6 +530,7 @@ int dispatch(const cv_gemm_params& p, hipStream_t st) {
   }
   if (swiglu && (tile == 0 || tile == 3)) tile = 1;
   if (tile == 3) return launch_ring<DT>(p, st);
+  if (tile == 4) return launch<DT, 128, 128, 2, 4>(p, st);  // 8 waves, wave tile 64x32
   if (tile == 0) return launch<DT, 128, 128>(p, st);
   if (tile == 1) return launch<DT, 128, 64>(p, st);
   return launch<DT, 64, 64>(p, st);
