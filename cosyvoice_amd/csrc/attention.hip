@@ -133,44 +133,67 @@ __global__ __launch_bounds__(256) void attn_kernel(const cv_attn_params p) {
       }
     }
 
-    // ---- scale, bias, masks, online softmax (per query = per lane column)
+    // ---- masks, online softmax (per query = per lane column).  The first version spent 730 VALU instructions per
+    // tile here (46 % of wave cycles, r01 PMC): now the max runs on raw scores (scale > 0 commutes with max), scale and
+    // max-subtraction fold into one fma feeding exp2, and interior tiles (every key below every query's limit) skip
+    // the per-element key-index compares altogether.
     uint4 pf[2][2];
+    const bool has_bias = p.bias != nullptr;
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       const int i = q0 + qt * 16 + lq;
       int jlim = klen;
       if (p.causal) jlim = min(jlim, i + p.causal_off + 1);
       if (p.chunk > 0) jlim = min(jlim, (i / p.chunk + 1) * p.chunk);
-      const bool has_bias = p.bias != nullptr;
-      const float* brow = has_bias ? p.bias + (int64_t)b * p.bias_bs + (int64_t)h * p.bias_hs + (int64_t)min(i, p.Tq - 1) * p.bias_ld : nullptr;
-      float mx = NEG_BIG;
+      const bool tile_full = __all(j0 + 64 <= jlim);
+      float mnew;
+      if (has_bias) {
+        const float* brow = p.bias + (int64_t)b * p.bias_bs + (int64_t)h * p.bias_hs + (int64_t)min(i, p.Tq - 1) * p.bias_ld;
+        float mx = NEG_BIG;
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
+        for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = j0 + kt * 16 + 4 * lg + r;
-          float v = sacc[kt][qt][r] * sc;
-          if (has_bias) v += brow[min(j, p.Tk - 1)] * 1.4426950408889634f;  // wave-uniform branch, clamped address
-          v = (j < jlim) ? v : NEG_BIG;
-          sacc[kt][qt][r] = v;
-          mx = fmaxf(mx, v);
+          for (int r = 0; r < 4; ++r) {
+            const int j = j0 + kt * 16 + 4 * lg + r;
+            float v = fmaf(sacc[kt][qt][r], sc, brow[min(j, p.Tk - 1)] * 1.4426950408889634f);
+            v = (j < jlim) ? v : NEG_BIG;
+            sacc[kt][qt][r] = v;
+            mx = fmaxf(mx, v);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mnew = fmaxf(mrun[qt], mx);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = exp2f(sacc[kt][qt][r] - mnew);
+      } else {
+        if (!tile_full) {
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int j = j0 + kt * 16 + 4 * lg + r;
+              sacc[kt][qt][r] = (j < jlim) ? sacc[kt][qt][r] : NEG_BIG;
+            }
         }
+        float mx = fmaxf(fmaxf(sacc[0][qt][0], sacc[0][qt][1]), fmaxf(sacc[0][qt][2], sacc[0][qt][3]));
+#pragma unroll
+        for (int kt = 1; kt < 4; ++kt)
+          mx = fmaxf(mx, fmaxf(fmaxf(sacc[kt][qt][0], sacc[kt][qt][1]), fmaxf(sacc[kt][qt][2], sacc[kt][qt][3])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mnew = fmaxf(mrun[qt], mx * sc);  // a fully masked slice gives NEG_BIG * sc: still far below any real score
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = exp2f(fmaf(sacc[kt][qt][r], sc, -mnew));
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mnew = fmaxf(mrun[qt], mx);
       const float alpha = exp2f(mrun[qt] - mnew);
       mrun[qt] = mnew;
       float ls = 0.f;
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = exp2f(sacc[kt][qt][r] - mnew);
-          sacc[kt][qt][r] = e;
-          ls += e;
-        }
-      }
+      for (int kt = 0; kt < 4; ++kt) ls += (sacc[kt][qt][0] + sacc[kt][qt][1]) + (sacc[kt][qt][2] + sacc[kt][qt][3]);
       lrun[qt] = lrun[qt] * alpha + ls;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
