@@ -119,7 +119,8 @@ EXPORTS = ["cv_version", "cv_arch", "cv_gemm", "cv_layernorm", "cv_attention",
            "cv_sizeof_gemm_params", "cv_sizeof_norm_params", "cv_sizeof_attn_params",
            "cv_to_channels_last", "cv_to_channels_first", "cv_snake_multi", "cv_stft16", "cv_istft16", "cv_hift_source",
            "cv_embedding", "cv_est_pack", "cv_cfm_update", "cv_graph_begin", "cv_graph_end", "cv_graph_launch",
-           "cv_graph_destroy", "cv_skinny_gemm", "cv_pack_skinny", "cv_rmsnorm_reduce", "cv_rope_append",
+           "cv_graph_destroy", "cv_graph_launch_direct", "cv_graph_num_launches", "cv_stream_create_cumask",
+           "cv_stream_destroy", "cv_skinny_gemm", "cv_pack_skinny", "cv_rmsnorm_reduce", "cv_rope_append",
            "cv_decode_attention", "cv_sample_ras", "cv_sizeof_skinny_params", "cv_sizeof_sample_params", "cv_anti_alias_act"]
 
 TORCH_DT = {torch.float32: CV_F32, torch.bfloat16: CV_BF16, torch.float16: CV_F16}

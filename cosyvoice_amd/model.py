@@ -49,6 +49,7 @@ class CosyVoice2Model:
         # high-priority side stream: the decode loop is a chain of short dependent kernels that must not queue behind the
         # flow GEMMs of the previous batch when both streams are busy (tts_batches)
         self.llm_context = torch.cuda.stream(torch.cuda.Stream(self.device, priority=-1))
+        self.llm_cu_slots = 12  # tts_batches: CU slots per XCD (of 32) owned by the decode loop; 0 = no partition
         self.lock = threading.Lock()
         self.tts_speech_token_dict = {}
         self.llm_end_dict = {}
@@ -167,12 +168,89 @@ class CosyVoice2Model:
         wav, _ = self.hift.inference(speech_feat=mel.contiguous(), cache_source=torch.zeros(1, 1, 0))
         return wav.cpu() if to_host else wav
 
+    def cu_partition(self, llm_cu_slots: int):
+        """(llm_stream, flow_stream): CU-masked streams giving the decode loop ``llm_cu_slots`` of the 32 CUs of every XCD
+        and flow + HiFT the rest (cached).  With both stages free to use all 256 CUs the decode step's short dependent
+        kernels queue behind — and share CUs with — the flow GEMMs and run 1.6x slower while the two overlap (measured:
+        226 -> 368 ms per batch, tools/cumask_probe2.py); on disjoint CU sets neither disturbs the other."""
+        from . import ops
+        if getattr(self, "_cu_partition_key", None) != llm_cu_slots:
+            k = llm_cu_slots
+            self._cu_partition = (ops.masked_stream(lambda s, x: s < k), ops.masked_stream(lambda s, x: s >= k))
+            self._cu_partition_key = k
+        return self._cu_partition
+
+    def tts_batches(self, batches, to_host: bool = True, llm_cu_slots: Optional[int] = None):
+        """Generator over a list of utterance batches (each a dict of tts_batch's arguments), software-pipelined the way
+        the reference overlaps its LLM thread with flow/HiFT (cli/model.py:62,119,189): the LLM decode of batch i+1
+        (latency-bound) runs while flow + HiFT of batch i (throughput-bound GEMMs) execute.  A batch may carry ``on_start``
+        (callable, e.g. the RCCL conditioning broadcast).
+
+        ``llm_cu_slots`` (default ``self.llm_cu_slots``) > 0 partitions the GPU: the decode loop runs on that many CUs
+        of every XCD and flow + HiFT on the others, each from its own host thread, every captured graph replayed launch by
+        launch (``ops.Graph.launch`` on a masked stream).  0 keeps both stages on all CUs (two plain streams)."""
+        k = self.llm_cu_slots if llm_cu_slots is None else llm_cu_slots
+        if k:
+            yield from self._tts_batches_partitioned(batches, to_host, k)
+        else:
+            yield from self._tts_batches_shared(batches, to_host)
+
+    def _flow_hift(self, b, toks):
+        n = len(toks[0])
+        assert all(len(t) == n for t in toks), "tts_batches needs equal generated lengths per batch"
+        tok = torch.tensor(toks, dtype=torch.int32, device=self.device)
+        mel = self.flow.inference_batch(tok, b["flow_prompt_speech_tokens"], b["prompt_speech_feats"], b["flow_embeddings"])
+        wav, _ = self.hift.inference(speech_feat=mel.contiguous(), cache_source=torch.zeros(1, 1, 0))
+        return wav
+
+    def _tts_batches_partitioned(self, batches, to_host, k):
+        from concurrent.futures import ThreadPoolExecutor
+        llm_part, flow_part = self.cu_partition(k)
+        llm_full = self.llm_context.stream  # all CUs: used while the other stage has nothing to run (pipeline fill / drain)
+        flow_full = torch.cuda.Stream(self.device)
+        caller = torch.cuda.current_stream()
+
+        def flow_job(b, toks, ready, stream):
+            with torch.no_grad(), torch.cuda.stream(stream):
+                stream.wait_event(ready)  # conditioning of this batch is in place
+                stream.wait_stream(flow_part if stream is flow_full else flow_full)  # workspaces of the previous batch
+                wav = self._flow_hift(b, toks)
+                if to_host:
+                    return wav.cpu(), None
+                done = torch.cuda.Event()
+                done.record(stream)
+                return wav, done
+
+        def collect(fut):
+            wav, done = fut.result()
+            if done is not None:
+                caller.wait_event(done)
+            return wav
+
+        it = iter(batches)
+        b = next(it, None)
+        pending = None
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            while b is not None:
+                stream = llm_part if pending is not None else llm_full
+                with torch.no_grad(), torch.cuda.stream(stream):
+                    stream.wait_stream(caller)  # inputs the caller produced on its own stream
+                    if b.get("on_start") is not None:
+                        b["on_start"]()  # e.g. the conditioning broadcast: issued on the LLM stream, never behind flow work
+                    ready = torch.cuda.Event()
+                    ready.record(stream)
+                    toks = self.llm.generate_batch(b["texts"], b["prompt_texts"], b["llm_prompt_speech_tokens"],
+                                                   forced=b.get("forced"), steps_per_poll=64)
+                nxt = next(it, None)
+                fut = pool.submit(flow_job, b, toks, ready, flow_part if nxt is not None else flow_full)
+                if pending is not None:
+                    yield collect(pending)
+                pending, b = fut, nxt
+            if pending is not None:
+                yield collect(pending)
+
     @torch.no_grad()
-    def tts_batches(self, batches, to_host: bool = True):
-        """Generator over a list of utterance batches (each a dict of tts_batch's arguments), software-pipelined over two
-        streams the way the reference overlaps its LLM thread with flow/HiFT (cli/model.py:62,119,189): the LLM decode of
-        batch i+1 (latency-bound graph replays, LLM side stream) runs while flow + HiFT of batch i (throughput-bound GEMMs,
-        caller's stream) execute.  A batch may carry ``on_start`` (callable, e.g. the RCCL conditioning broadcast)."""
+    def _tts_batches_shared(self, batches, to_host):
         llm_stream = self.llm_context.stream if hasattr(self.llm_context, "stream") else torch.cuda.Stream()
         pending = None
         for b in list(batches) + [None]:
@@ -180,7 +258,7 @@ class CosyVoice2Model:
             if b is not None:
                 with torch.cuda.stream(llm_stream):
                     if b.get("on_start") is not None:
-                        b["on_start"]()  # e.g. the conditioning broadcast: issued on the LLM stream, never behind flow work
+                        b["on_start"]()
                     ready = torch.cuda.Event()
                     ready.record(llm_stream)
                     toks = self.llm.generate_batch(b["texts"], b["prompt_texts"], b["llm_prompt_speech_tokens"], forced=b.get("forced"))
@@ -188,10 +266,5 @@ class CosyVoice2Model:
                 yield pending.cpu() if to_host else pending.clone()
                 pending = None
             if toks is not None:
-                n = len(toks[0])
-                assert all(len(t) == n for t in toks), "tts_batches needs equal generated lengths per batch"
                 torch.cuda.current_stream().wait_event(ready)  # conditioning of this batch is in place
-                tok = torch.tensor(toks, dtype=torch.int32, device=self.device)
-                mel = self.flow.inference_batch(tok, b["flow_prompt_speech_tokens"], b["prompt_speech_feats"], b["flow_embeddings"])
-                wav, _ = self.hift.inference(speech_feat=mel.contiguous(), cache_source=torch.zeros(1, 1, 0))
-                pending = wav
+                pending = self._flow_hift(b, toks)

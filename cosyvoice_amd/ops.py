@@ -197,7 +197,19 @@ class Graph:
         return self
 
     def launch(self):
-        L.check(L.lib().cv_graph_launch(self.handle, L.stream_ptr()), "cv_graph_launch")
+        """Replay on torch's current stream: as a hipGraphExec, or — when that stream is CU-masked (``masked_stream``) —
+        launch by launch, because hipGraph replays ignore a stream's CU mask."""
+        if torch.cuda.current_stream().cuda_stream in _MASKED_STREAMS:
+            L.check(L.lib().cv_graph_launch_direct(self.handle, L.stream_ptr()), "cv_graph_launch_direct")
+        else:
+            L.check(L.lib().cv_graph_launch(self.handle, L.stream_ptr()), "cv_graph_launch")
+
+    def launch_direct(self):
+        L.check(L.lib().cv_graph_launch_direct(self.handle, L.stream_ptr()), "cv_graph_launch_direct")
+
+    @property
+    def num_launches(self):
+        return L.lib().cv_graph_num_launches(self.handle)
 
     def __del__(self):
         try:
@@ -205,6 +217,28 @@ class Graph:
                 L.lib().cv_graph_destroy(self.handle)
         except Exception:
             pass
+
+
+_MASKED_STREAMS = set()  # raw handles of the CU-masked streams made here: Graph.launch issues direct launches on them
+
+
+def masked_stream(keep, n_xcd=8, slots=32, device=None):
+    """Stream restricted to the CUs for which ``keep(slot, xcd)`` is true (slot 0..slots-1 within XCD 0..n_xcd-1).
+    Mask bit i = (xcd i % n_xcd, slot i // n_xcd) — KFD's symmetric CU-mask mapping, confirmed on MI355X by timing.
+    Every XCD must keep at least one CU (an XCD with an empty mask falls back to all of its CUs)."""
+    n = n_xcd * slots
+    words = (C.c_uint32 * ((n + 31) // 32))()
+    for i in range(n):
+        if keep(i // n_xcd, i % n_xcd):
+            words[i // 32] |= 1 << (i % 32)
+    for x in range(n_xcd):
+        if not any(keep(s, x) for s in range(slots)):
+            raise ValueError(f"CU mask leaves XCD {x} empty")
+    st = C.c_void_p()
+    L.check(L.lib().cv_stream_create_cumask(words, len(words), C.byref(st)), "cv_stream_create_cumask")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    _MASKED_STREAMS.add(st.value)
+    return torch.cuda.ExternalStream(st.value, device=dev)
 
 
 # ----------------------------------------------------------------------------- LLM decode helpers

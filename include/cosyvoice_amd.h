@@ -156,9 +156,18 @@ int cv_cfm_update(float* x, const float* v, int32_t B, int32_t T, int32_t C, flo
  * torch.cuda.CUDAGraph capture in llm/qwen2_5.py:97-124).  begin/end bracket the launches; launch replays them.
  * ------------------------------------------------------------------------------------------ */
 int cv_graph_begin(void* stream);
-int cv_graph_end(void* stream, void** graph_exec_out);
-int cv_graph_launch(void* graph_exec, void* stream);
-int cv_graph_destroy(void* graph_exec);
+int cv_graph_end(void* stream, void** graph_out);
+int cv_graph_launch(void* graph, void* stream);
+/* The same launch sequence issued one by one (hipLaunchKernel per captured node) instead of as a hipGraphExec replay:
+ * hipGraph replays ignore the CU mask of the stream they run on, direct launches honour it.  Used to give the decode loop
+ * (the reference's LLM thread, cli/model.py:119) and the flow/vocoder stages (the caller's thread) disjoint CU sets.
+ * cv_graph_num_launches: length of that list, or CV_ERR_UNSUPPORTED when the capture holds a node kind it cannot replay. */
+int cv_graph_launch_direct(void* graph, void* stream);
+int cv_graph_num_launches(void* graph);
+int cv_graph_destroy(void* graph);
+/* Stream restricted to the CUs of `mask` (nwords x 32 bits; bit i = CU slot i / 8 of XCD i % 8 on an 8-XCD part). */
+int cv_stream_create_cumask(const uint32_t* mask, int32_t nwords, void** stream_out);
+int cv_stream_destroy(void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * LLM decode-step kernels (Qwen2 backbone; HF Qwen2ForCausalLM called from llm/llm.py:754-766; the reference's own

@@ -70,3 +70,35 @@ def test_tts_batch_matches_single_with_forced_tokens():
     for b in range(B):
         mel_1 = m.flow.inference_batch(tok[b:b + 1], shared["flow_prompt_speech_token"], shared["prompt_speech_feat"], shared["flow_embedding"])
         assert (mel_1[0] - mel_b[b]).abs().max().item() < 1e-4
+
+
+@pytest.mark.gpu
+def test_tts_batches_cu_partition_equals_shared_streams():
+    """The CU-partitioned pipeline (decode loop and flow/HiFT on disjoint CU-masked streams, graphs replayed launch by
+    launch from two host threads) produces bit-identical waveforms to the two-plain-streams pipeline."""
+    m, lc, fc, hc = _model()
+    B, nb = 2, 3
+    shared = _inputs(lc, fc, seed=0)
+    g = torch.Generator().manual_seed(11)
+
+    def batches():
+        out = []
+        for i in range(nb):
+            ins = [_inputs(lc, fc, seed=10 * i + s) for s in range(B)]
+            forced = [torch.randint(0, lc.speech_token_size, (14,), generator=torch.Generator().manual_seed(100 + i)).tolist()] * B
+            out.append(dict(texts=[x["text"].cuda() for x in ins], prompt_texts=[shared["prompt_text"].cuda()] * B,
+                            llm_prompt_speech_tokens=[shared["llm_prompt_speech_token"].cuda()] * B,
+                            flow_prompt_speech_tokens=shared["flow_prompt_speech_token"].cuda().expand(B, -1),
+                            prompt_speech_feats=shared["prompt_speech_feat"].cuda().expand(B, -1, -1),
+                            flow_embeddings=shared["flow_embedding"].cuda().expand(B, -1), forced=forced))
+        return out
+
+    torch.manual_seed(0)
+    ref = [w.clone() for w in m.tts_batches(batches(), llm_cu_slots=0)]
+    for k, to_host in ((12, True), (4, False)):
+        torch.manual_seed(0)
+        got = [w.cpu().clone() for w in m.tts_batches(batches(), to_host=to_host, llm_cu_slots=k)]
+        assert len(got) == nb
+        for a, b in zip(ref, got):
+            assert a.shape == b.shape and torch.isfinite(b).all()
+            assert torch.equal(a, b)
