@@ -76,6 +76,7 @@ class SkinnyParams(C.Structure):
         ("nslabs", _vp), ("n_nslab", _i32), ("nslab_stride", _i64), ("ld_nslab", _i32),
         ("ngamma", _vp), ("neps", _f32),
         ("nx_out", _vp),
+        ("max_wgs", _i32),
     ]
 
 

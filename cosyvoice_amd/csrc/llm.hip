@@ -1,6 +1,7 @@
 // LLM decode-step kernels for gfx950: skinny MFMA GEMM over pre-packed weights (HBM-bound weight streaming),
 // RMSNorm with split-K slab reduction, RoPE + KV append, single-query GQA attention, on-device RAS sampling.
 #include "cv_device.h"
+#include <algorithm>
 
 namespace {
 
@@ -36,10 +37,16 @@ __global__ __launch_bounds__(256) void pack_skinny_kernel(const uint16_t* W, uin
 // fragments (1 KiB per wave-load, non-temporal) straight into MFMA B operands and reduces through LDS at the end.
 // NORM: the activation operand is produced in the prologue (residual + split-K slabs -> RMSNorm -> 16-bit, staged in
 // LDS in fragment order); the weight loads of the first chunk are issued BEFORE the prologue so HBM latency hides under it.
-// NORM: 0 = A from global memory, 1 = fused RMSNorm prologue, 2 = prologue + split-K slab reduction.
+// NORM: 0 = A from global memory, 1 + n = fused RMSNorm prologue that first adds n split-K slabs to the residual row.
 // TPR = threads per activation row in the prologue (256/TPR rows): 64 for M <= 4, 32 for M <= 8, 16 otherwise.
-template <int DT, int TPW, int NORM, int TPR>
-__global__ __launch_bounds__(256) void skinny_kernel(const cv_skinny_params p) {
+// U = weight fragments a wave keeps in flight per tile (one batch of loads per U k-steps): 8 covers K <= 1024 in a
+// single round trip, 16 does the same for the down projection's longer slices.
+// Register diet for the gate/up form (TPW = 2): at 197 VGPRs two workgroups fit a CU, so on the ~100 CUs the pipeline
+// leaves the decode loop its 304 workgroups ran as two rounds (11.2 us instead of 7.3).  Gamma is staged through LDS and
+// read back just in time, the K = 896 slices use clamp-free immediate-offset loads (U = 7), and the kernel is bounded to
+// 168 VGPRs = three workgroups per CU: one round on 104 CUs, 16 stragglers on 96.
+template <int DT, int TPW, int NORM, int TPR, int U>
+__global__ __launch_bounds__(256, ((TPW == 2 && TPR >= 32) ? 3 : 2)) void skinny_kernel(const cv_skinny_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float (*red)[TPW][64][4] = (float (*)[TPW][64][4])smem;           // [4][TPW][64][4]
   char* aimg = smem + 4 * TPW * 64 * 4 * sizeof(float);             // NORM: [nks][64 lanes][16 B]
@@ -55,7 +62,6 @@ __global__ __launch_bounds__(256) void skinny_kernel(const cv_skinny_params p) {
 #pragma unroll
   for (int t = 0; t < TPW; ++t) Wt[t] = (const uint4*)p.Wp + (int64_t)(tile0 + t) * nks * 64 + lane;
 
-  constexpr int U = 8;
   uint4 w[TPW][U];
   auto load_w = [&](int ks) {
 #pragma unroll
@@ -63,10 +69,28 @@ __global__ __launch_bounds__(256) void skinny_kernel(const cv_skinny_params p) {
 #pragma unroll
       for (int t = 0; t < TPW; ++t) {
         // unconditional (clamped) load: a branch per element would serialise the stream with vmcnt(0) waits
-        const int kk = (ks + u < w1) ? ks + u : max(w1 - 1, 0);
+        // U == 7: the host picked it because every wave's slice is exactly 7 k-steps (K = 896): no clamp, so the loads are
+        // one base address + immediate offsets instead of 16 computed 64-bit addresses held in registers
+        const int kk = (U == 7) ? ks + u : ((ks + u < w1) ? ks + u : max(w1 - 1, 0));
         w[t][u] = nt_load16(Wt[t] + (int64_t)kk * 64);
       }
   };
+
+  // mode 1 (out += A W^T): the residual values this lane will update are fetched now, with the weights, instead of
+  // after the reduction (one dependent HBM round trip less on the kernel's critical path)
+  float resid[TPW][4];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) resid[t][r] = 0.f;
+  if (p.mode == 1 && wid == 0) {
+    const int m = min(lane & 15, p.M - 1);
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        resid[t][r] = p.out_f32[(int64_t)m * p.ldo + min((tile0 + t) * 16 + 4 * (lane >> 4) + r, p.N - 1)];
+  }
 
   if constexpr (NORM != 0) {
     // TPR threads per row; thread handles float4 columns c = sub + TPR i.  Every load is unconditional (rows >= M and
@@ -80,23 +104,28 @@ __global__ __launch_bounds__(256) void skinny_kernel(const cv_skinny_params p) {
     float4 v[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = *(const float4*)(xr + min(sub + TPR * i, nq - 1) * 4);
-    if constexpr (NORM == 2) {
+    if constexpr (NORM > 1) {
       const float* sl = p.nslabs + (int64_t)rowc * p.ld_nslab;
 #pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) {
-        // slab index clamped, contribution weighted 0/1: no branch around the loads
-        const float wgt = s2 < p.n_nslab ? 1.f : 0.f;
-        const float* sp = sl + (int64_t)min(s2, p.n_nslab - 1) * p.nslab_stride;
+      for (int s2 = 0; s2 < NORM - 1; ++s2) {
+        const float* sp = sl + (int64_t)s2 * p.nslab_stride;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
           const float4 q = *(const float4*)(sp + min(sub + TPR * i, nq - 1) * 4);
-          v[i].x += wgt * q.x; v[i].y += wgt * q.y; v[i].z += wgt * q.z; v[i].w += wgt * q.w;
+          v[i].x += q.x; v[i].y += q.y; v[i].z += q.z; v[i].w += q.w;
         }
       }
     }
-    float4 gm[NV];
+    constexpr bool GAMMA_LDS = TPW == 2;  // the occupancy-bound form; the others keep gamma in registers (one barrier less)
+    float4 gm[GAMMA_LDS ? 1 : NV];
+    if constexpr (GAMMA_LDS) {
+      float* sgam = (float*)smem;  // the reduction scratch is free until the MFMAs are done (K <= 1024 floats fit)
+      const float4 g4 = *(const float4*)(p.ngamma + min(tid, nq - 1) * 4);
+      if (tid < nq) *(float4*)(sgam + tid * 4) = g4;
+    } else {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) gm[i] = *(const float4*)(p.ngamma + min(sub + TPR * i, nq - 1) * 4);
+      for (int i = 0; i < NV; ++i) gm[i] = *(const float4*)(p.ngamma + min(sub + TPR * i, nq - 1) * 4);
+    }
     load_w(w0);  // weight stream issued behind the (L2-resident) activation loads; it lands during the norm arithmetic
     float ss = 0.f;
 #pragma unroll
@@ -108,14 +137,18 @@ __global__ __launch_bounds__(256) void skinny_kernel(const cv_skinny_params p) {
     for (int o = TPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     const float rstd = rsqrtf(ss / (float)p.K + p.neps);
     const bool writer = p.nx_out && blockIdx.x == 0 && blockIdx.y == 0 && live;
+    if constexpr (GAMMA_LDS) __syncthreads();  // gamma staged
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = sub + TPR * i;
       if (c >= nq) continue;
+      float4 gmi;
+      if constexpr (GAMMA_LDS) gmi = *(const float4*)((const float*)smem + c * 4);
+      else gmi = gm[i];
       uint2 u = make_uint2(0, 0);
       if (live) {
-        u.x = pack2<DT>(v[i].x * rstd * gm[i].x, v[i].y * rstd * gm[i].y);
-        u.y = pack2<DT>(v[i].z * rstd * gm[i].z, v[i].w * rstd * gm[i].w);
+        u.x = pack2<DT>(v[i].x * rstd * gmi.x, v[i].y * rstd * gmi.y);
+        u.y = pack2<DT>(v[i].z * rstd * gmi.z, v[i].w * rstd * gmi.w);
       }
       if (writer) *(float4*)(p.nx_out + (int64_t)row * p.ldnx + c * 4) = v[i];
       // element k0 = 4c: chunk kc = c >> 1 (8 elements), half = c & 1; fragment slot (ks = kc >> 2, g = kc & 3, row)
@@ -137,7 +170,10 @@ __global__ __launch_bounds__(256) void skinny_kernel(const cv_skinny_params p) {
     load_w(w0);
   }
 
-  const uint16_t* Arow = (NORM != 0) ? nullptr : (const uint16_t*)p.A + (int64_t)(lane & 15) * p.lda + 8 * (lane >> 4);
+  // rows >= M are not fetched (their lanes re-read row M-1, the same cache lines, and are masked to zero): for M = 8 that
+  // halves the activation traffic, which per workgroup is as large as the weight slice itself
+  const uint16_t* Arow = (NORM != 0) ? nullptr : (const uint16_t*)p.A + (int64_t)min(lane & 15, p.M - 1) * p.lda + 8 * (lane >> 4);
+  const uint32_t rowmask = (lane & 15) < p.M ? 0xFFFFFFFFu : 0u;
   f32x4_t acc[TPW];
 #pragma unroll
   for (int t = 0; t < TPW; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -148,12 +184,12 @@ __global__ __launch_bounds__(256) void skinny_kernel(const cv_skinny_params p) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       // unconditional clamped load, masked to zero beyond the slice (the clamped weight fragment then contributes 0)
-      const bool ok = ks + u < w1;
+      const bool ok = (U == 7) || (ks + u < w1);
       const int kk = ok ? ks + u : max(w1 - 1, 0);
       uint4 t;
       if constexpr (NORM != 0) t = *(const uint4*)(aimg + ((kk * 64 + lane) << 4));
       else t = *(const uint4*)(Arow + kk * 32);
-      const uint32_t msk = ok ? 0xFFFFFFFFu : 0u;
+      const uint32_t msk = ok ? ((NORM != 0) ? 0xFFFFFFFFu : rowmask) : 0u;
       a[u] = make_uint4(t.x & msk, t.y & msk, t.z & msk, t.w & msk);
     }
 #pragma unroll
@@ -203,9 +239,213 @@ __global__ __launch_bounds__(256) void skinny_kernel(const cv_skinny_params p) {
       if (n >= p.N) continue;
       float o = v[t][r];
       if (p.bias && blockIdx.y == 0) o += p.bias[n];
-      if (p.mode == 1) p.out_f32[(int64_t)m * p.ldo + n] += o;
+      if (p.mode == 1) p.out_f32[(int64_t)m * p.ldo + n] = resid[t][r] + o;
       else p.out_f32[(int64_t)blockIdx.y * p.slab_stride + (int64_t)m * p.ldo + n] = o;
     }
+  }
+}
+
+// =========================================================================================== streaming skinny GEMM
+// The decode step's form of the kernel above (every wave's K slice fits one batch of U fragment loads): a workgroup walks
+// tile groups g = blockIdx.x, += gridDim.x with the NEXT group's weight fragments already in flight (two register sets,
+// loads never conditional), so a CU keeps an HBM stream going instead of
+// paying one cold round trip per workgroup — what matters when the decode loop owns 64-96 CUs (tts_batches' CU partition:
+// 304 single-shot workgroups on 96 CUs ran as two full rounds, 11.2 us; see tools/llm_kernel_bench.py) and harmless with
+// one group per workgroup.  The norm prologue and the activation fragments are produced once per workgroup.
+// LOOP = false: one group per workgroup (grid = groups): no second register set, no dummy loads.
+template <int DT, int TPW, int NORM, int TPR, int U, bool LOOP>
+__global__ __launch_bounds__(256) void skinny_stream_kernel(const cv_skinny_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4 (*red)[4][TPW][64] = (float4 (*)[4][TPW][64])smem;            // [LOOP ? 2 : 1][4][TPW][64]
+  char* aimg = smem + (LOOP ? 2 : 1) * 4 * TPW * 64 * sizeof(float4);   // NORM: [nks][64 lanes][16 B]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int nks = p.K >> 5;
+  const int per = (nks + p.ksplit - 1) / p.ksplit;
+  const int kb = blockIdx.y * per, ke = min(nks, kb + per);
+  const int cnt = max(ke - kb, 0), pw = (cnt + 3) >> 2;
+  const int w0 = kb + wid * pw, w1 = min(ke, w0 + pw);   // w1 - w0 <= U (host-checked)
+  const int ngroups = ((p.N + 15) / 16) / TPW;
+  const int stride = gridDim.x;
+  const uint4* Wbase = (const uint4*)p.Wp + lane;
+
+  auto load_group = [&](uint4 (&w)[TPW][U], float (&rs)[TPW][4], int g) {
+    // never conditional, never a shared dummy line (2432 waves hitting one KiB serialise on its channel): a k-step past
+    // the slice re-reads the wave's last fragment, a group past the end re-reads the group being computed (L2 hits)
+    const int gs = g < ngroups ? g : g - stride;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const int kk = (w0 + u < w1) ? w0 + u : max(w1 - 1, 0);
+        w[t][u] = nt_load16(Wbase + ((int64_t)(gs * TPW + t) * nks + kk) * 64);
+      }
+    if (p.mode == 1) {  // kernel-uniform: the residual values of group g, fetched with its weights
+      const int gc = min(g, ngroups - 1), m = min(lane & 15, p.M - 1);
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          rs[t][r] = p.out_f32[(int64_t)m * p.ldo + min((gc * TPW + t) * 16 + 4 * (lane >> 4) + r, p.N - 1)];
+    }
+  };
+
+  uint4 wA[TPW][U], wB[TPW][U];
+  float rA[TPW][4], rB[TPW][4];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rA[t][r] = rB[t][r] = 0.f;
+
+  if constexpr (NORM != 0) {
+    constexpr int NV = 256 / TPR;  // float4 per thread for K <= 1024
+    const int row = tid / TPR, sub = tid % TPR;
+    const int nq = p.K >> 2;
+    const bool live = row < p.M;
+    const int rowc = live ? row : 0;
+    const float* xr = p.nx + (int64_t)rowc * p.ldnx;
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = *(const float4*)(xr + min(sub + TPR * i, nq - 1) * 4);
+    if constexpr (NORM > 1) {
+      const float* sl = p.nslabs + (int64_t)rowc * p.ld_nslab;
+#pragma unroll
+      for (int s2 = 0; s2 < NORM - 1; ++s2) {
+        const float* sp = sl + (int64_t)s2 * p.nslab_stride;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const float4 q = *(const float4*)(sp + min(sub + TPR * i, nq - 1) * 4);
+          v[i].x += q.x; v[i].y += q.y; v[i].z += q.z; v[i].w += q.w;
+        }
+      }
+    }
+    float4 gm[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) gm[i] = *(const float4*)(p.ngamma + min(sub + TPR * i, nq - 1) * 4);
+    load_group(wA, rA, blockIdx.x);  // behind the (L2-resident) activation loads; lands during the norm arithmetic
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float msk = (sub + TPR * i < nq && live) ? 1.f : 0.f;
+      ss += msk * (v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+#pragma unroll
+    for (int o = TPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float rstd = rsqrtf(ss / (float)p.K + p.neps);
+    const bool writer = p.nx_out && blockIdx.x == 0 && blockIdx.y == 0 && live;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = sub + TPR * i;
+      if (c >= nq) continue;
+      uint2 u = make_uint2(0, 0);
+      if (live) {
+        u.x = pack2<DT>(v[i].x * rstd * gm[i].x, v[i].y * rstd * gm[i].y);
+        u.y = pack2<DT>(v[i].z * rstd * gm[i].z, v[i].w * rstd * gm[i].w);
+      }
+      if (writer) *(float4*)(p.nx_out + (int64_t)row * p.ldnx + c * 4) = v[i];
+      const int kc = c >> 1;
+      *(uint2*)(aimg + ((((kc >> 2) * 64) + (kc & 3) * 16 + row) << 4) + (c & 1) * 8) = u;
+    }
+    if constexpr (TPR > 16) {
+      constexpr int ROWS = 256 / TPR;
+      for (int idx = tid; idx < nks * 4 * (16 - ROWS); idx += 256) {
+        const int r_ = ROWS + idx % (16 - ROWS), kg = idx / (16 - ROWS);
+        *(uint4*)(aimg + (((kg >> 2) * 64 + (kg & 3) * 16 + r_) << 4)) = make_uint4(0, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  } else {
+    load_group(wA, rA, blockIdx.x);
+  }
+
+  // activation fragments of this wave's K slice: the same for every group, read once
+  uint4 a[U];
+  {
+    const uint16_t* Arow = (NORM != 0) ? nullptr : (const uint16_t*)p.A + (int64_t)min(lane & 15, p.M - 1) * p.lda + 8 * (lane >> 4);
+    const uint32_t rowmask = ((NORM != 0) || (lane & 15) < p.M) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = w0 + u < w1;
+      const int kk = ok ? w0 + u : max(w1 - 1, 0);
+      uint4 t;
+      if constexpr (NORM != 0) t = *(const uint4*)(aimg + ((min(kk, nks - 1) * 64 + lane) << 4));
+      else t = *(const uint4*)(Arow + min(kk, nks - 1) * 32);
+      const uint32_t msk = ok ? rowmask : 0u;
+      a[u] = make_uint4(t.x & msk, t.y & msk, t.z & msk, t.w & msk);
+    }
+  }
+
+  int it = 0;
+  auto compute = [&](uint4 (&w)[TPW][U], float (&rs)[TPW][4], int g) {
+    f32x4_t acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) acc[t] = mfma_block<DT>(w[t][u], a[u], acc[t]);
+    const int buf = it & 1;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) red[buf][wid][t][lane] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    __syncthreads();
+    if (wid == (it & 3)) {  // the epilogue rotates over the waves; the others run ahead into the next group
+      float v[TPW][4];
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const float4 q0 = red[buf][0][t][lane], q1 = red[buf][1][t][lane], q2 = red[buf][2][t][lane], q3 = red[buf][3][t][lane];
+        v[t][0] = q0.x + q1.x + q2.x + q3.x; v[t][1] = q0.y + q1.y + q2.y + q3.y;
+        v[t][2] = q0.z + q1.z + q2.z + q3.z; v[t][3] = q0.w + q1.w + q2.w + q3.w;
+      }
+      const int m = lane & 15, gq = lane >> 4;
+      const int tile0 = g * TPW;
+      if (m < p.M) {
+        if (p.mode == 2) {
+          if constexpr (TPW == 2) {
+            const int nb = tile0 * 16 + 4 * gq;
+            const int hcol = (tile0 >> 1) * 16 + 4 * gq;
+            float h[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float gt = v[0][r], up = v[1][r];
+              if (p.bias) { gt += p.bias[nb + r]; up += p.bias[nb + 16 + r]; }
+              h[r] = act_silu(gt) * up;
+            }
+            uint2 u;
+            u.x = pack2<DT>(h[0], h[1]);
+            u.y = pack2<DT>(h[2], h[3]);
+            *(uint2*)((uint16_t*)p.out_act + (int64_t)m * p.ldoa + hcol) = u;
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) {
+            const int nb = (tile0 + t) * 16 + 4 * gq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int n = nb + r;
+              if (n >= p.N) continue;
+              float o = v[t][r];
+              if (p.bias && blockIdx.y == 0) o += p.bias[n];
+              if (p.mode == 1) p.out_f32[(int64_t)m * p.ldo + n] = rs[t][r] + o;
+              else p.out_f32[(int64_t)blockIdx.y * p.slab_stride + (int64_t)m * p.ldo + n] = o;
+            }
+          }
+        }
+      }
+    }
+    ++it;
+  };
+
+  if constexpr (!LOOP) {
+    compute(wA, rA, blockIdx.x);
+    return;
+  }
+  for (int g = blockIdx.x; g < ngroups;) {
+    load_group(wB, rB, g + stride);
+    compute(wA, rA, g);
+    g += stride;
+    if (g >= ngroups) break;
+    load_group(wA, rA, g + stride);
+    compute(wB, rB, g);
+    g += stride;
   }
 }
 
@@ -295,85 +535,40 @@ __global__ __launch_bounds__(256) void rope_append_kernel(const float* qkv, int 
 constexpr float NEG_BIG = -1e30f;
 constexpr int DA_WAVES = 8;
 
-template <int DT>
+// One workgroup per (kv head, sequence); every wave owns key tiles wid, wid + 8 (64 keys each) and issues the loads of BOTH
+// at kernel entry, together with the qkv row — nothing on the K/V stream waits for the new token: its roped K row and V
+// column are exchanged through LDS and patched into the fragments of the wave whose tile holds position `pos`, while the
+// global append happens on the side for later steps.  (The first version stored the new K/V, fenced and read them back,
+// and loaded a wave's second tile only after finishing its first: two more dependent HBM round trips, 8.5 us per call.)
+// FUSED is a template parameter, not `qkv != nullptr` at run time: a run-time branch around the qkv loads ends in PHIs
+// with the zero defaults, and hipcc then waits for those loads before it issues the K/V tile loads.
+template <int DT, bool FUSED>
 __global__ __launch_bounds__(512) void decode_attn_kernel(const uint16_t* q, int ldq, uint16_t* kcache, uint16_t* vtcache,
                                                           const int32_t* ctx_len, int ctx_add, uint16_t* out, int ldo, int Hq, int Hkv,
                                                           int ctx_max, float scale, const float* qkv, int ldqkv, const float* inv_freq) {
   __shared__ float s_m[DA_WAVES][16], s_l[DA_WAVES][16];
   __shared__ float s_o[DA_WAVES][64][17];  // [wave][d][query col] (+1 pad)
+  __shared__ __attribute__((aligned(16))) uint16_t s_newk[64], s_newv[64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lq = lane & 15, lg = lane >> 4;
   const int hk = blockIdx.x, b = blockIdx.y;
   const int G = Hq / Hkv;  // query heads per kv head (<= 16)
-  const int pos = ctx_len[b];
-  const int ctx = min(pos + ctx_add, ctx_max);
   uint16_t* Kb = kcache + ((int64_t)b * Hkv + hk) * ctx_max * 64;
   uint16_t* Vb = vtcache + ((int64_t)b * Hkv + hk) * 64 * ctx_max;
+  const int pos = ctx_len[b];
+  const int ctx = min(pos + ctx_add, ctx_max);
 
-  // Q fragments: column lq = query head hk*G + lq (zero beyond the group); d chunks (ks*4 + lg)*8
-  uint4 qf[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-  if (qkv) {
-    // fused RoPE (HF rotate_half: pairs (d, d+32)); a lane owns d in [8 lg, 8 lg + 8) and the partners + 32
-    const float* row = qkv + (int64_t)b * ldqkv;
-    if (lq < G) {
-      const float* src = row + (hk * G + lq) * 64 + 8 * lg;
-      float lo[8], hi[8];
-      const float* cs_row = inv_freq + (int64_t)min(pos, ctx_max - 1) * 64;  // [pos][cos 32 | sin 32] table
-      const float4 c0 = *(const float4*)(cs_row + 8 * lg), c1 = *(const float4*)(cs_row + 8 * lg + 4);
-      const float4 s0 = *(const float4*)(cs_row + 32 + 8 * lg), s1 = *(const float4*)(cs_row + 32 + 8 * lg + 4);
-      const float4 a0 = *(const float4*)(src), a1 = *(const float4*)(src + 4);
-      const float4 b0 = *(const float4*)(src + 32), b1 = *(const float4*)(src + 36);
-      const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-      const float sn_[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-      const float x1_[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-      const float x2_[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        lo[j] = x1_[j] * cc[j] - x2_[j] * sn_[j];
-        hi[j] = x2_[j] * cc[j] + x1_[j] * sn_[j];
-      }
-      qf[0] = make_uint4(pack2<DT>(lo[0], lo[1]), pack2<DT>(lo[2], lo[3]), pack2<DT>(lo[4], lo[5]), pack2<DT>(lo[6], lo[7]));
-      qf[1] = make_uint4(pack2<DT>(hi[0], hi[1]), pack2<DT>(hi[2], hi[3]), pack2<DT>(hi[4], hi[5]), pack2<DT>(hi[6], hi[7]));
-    }
-    // append K (roped) and V^T of this kv head at position pos: wave 0 lanes 0..31 -> K pairs, wave 1 -> V
-    if (pos < ctx_max) {
-      if (wid == 0 && lane < 32) {
-        const float* ks_ = row + Hq * 64 + hk * 64;
-        const float cs = inv_freq[(int64_t)pos * 64 + lane], sn = inv_freq[(int64_t)pos * 64 + 32 + lane];
-        const float x1 = ks_[lane], x2 = ks_[lane + 32];
-        Kb[(int64_t)pos * 64 + lane] = Elem16<DT>::from_f32(x1 * cs - x2 * sn);
-        Kb[(int64_t)pos * 64 + lane + 32] = Elem16<DT>::from_f32(x2 * cs + x1 * sn);
-      } else if (wid == 1) {
-        Vb[(int64_t)lane * ctx_max + pos] = Elem16<DT>::from_f32(row[(Hq + Hkv) * 64 + hk * 64 + lane]);
-      }
-    }
-    __threadfence_block();
-    __syncthreads();
-  } else {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-      if (lq < G) qf[ks] = *(const uint4*)(q + (int64_t)b * ldq + (hk * G + lq) * 64 + (ks * 4 + lg) * 8);
-  }
-
-  f32x4_t oacc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) oacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float mrun = NEG_BIG, lrun = 0.f;
-  const float sc = scale * 1.4426950408889634f;
-  const int ntiles = (ctx + 63) >> 6;
-
-  for (int t = wid; t < ntiles; t += DA_WAVES) {
-    const int j0 = t << 6;
-    // issue every load of the tile up front (K: 8 x 16 B, V^T: 16 x 8 B per lane)
-    uint4 kf[4][2];
+  // ---- loads of a tile pair: unconditional (rows beyond the cache end are clamped; invalid keys are masked later)
+  uint4 kfA[4][2], kfB[4][2];
+  uint2 vfA[4][2][2], vfB[4][2][2];
+  auto load_tile = [&](uint4 (&kf)[4][2], uint2 (&vf)[4][2][2], int t) __attribute__((always_inline)) {
+    const int j0 = min(t << 6, ctx_max - 64);
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      // unconditional: rows beyond ctx hold finite stale / zero data and their scores are masked below
-      const int key = min(j0 + kt * 16 + lq, ctx_max - 1);
+      const int key = j0 + kt * 16 + lq;
       kf[kt][0] = *(const uint4*)(Kb + (int64_t)key * 64 + lg * 8);
       kf[kt][1] = *(const uint4*)(Kb + (int64_t)key * 64 + 32 + lg * 8);
     }
-    uint2 vf[4][2][2];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       const uint16_t* vrow = Vb + (int64_t)(dt * 16 + lq) * ctx_max + j0 + 4 * lg;
@@ -382,6 +577,114 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(const uint16_t* q, int
         // the cache is zero-initialised and only ever holds finite values: stale keys beyond ctx meet P == 0
         vf[dt][s2][0] = *(const uint2*)(vrow + 32 * s2);
         vf[dt][s2][1] = *(const uint2*)(vrow + 32 * s2 + 16);
+      }
+    }
+  };
+  auto load_tiles = [&](int t0) __attribute__((always_inline)) {
+    load_tile(kfA, vfA, t0);
+    load_tile(kfB, vfB, t0 + DA_WAVES);
+  };
+
+  // Q fragments: column lq = query head hk*G + lq (zero beyond the group); d chunks (ks*4 + lg)*8
+  uint4 qf[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+  constexpr bool fused = FUSED;
+  // fused RoPE (HF rotate_half: pairs (d, d+32)); a lane owns d in [8 lg, 8 lg + 8) and the partners + 32.  Every lane
+  // loads (clamped head index) so the loads stay unconditional; lanes beyond the group zero their fragment afterwards.
+  // Issue order = return order: the small qkv / rope-table words first, then the K/V tiles, so the rope arithmetic and the
+  // LDS exchange run while the tiles are still in flight.
+  const int ntiles = (ctx + 63) >> 6;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, b0 = a0, b1 = a0, c0 = a0, c1 = a0, s0 = a0, s1 = a0;
+  float kx1 = 0.f, kx2 = 0.f, vx = 0.f, kcs = 0.f, ksn = 0.f;
+  if constexpr (FUSED) {
+    const float* row = qkv + (int64_t)b * ldqkv;
+    const float* src = row + (hk * G + min(lq, G - 1)) * 64 + 8 * lg;
+    a0 = *(const float4*)(src); a1 = *(const float4*)(src + 4);
+    b0 = *(const float4*)(src + 32); b1 = *(const float4*)(src + 36);
+    // new K (wave 0: d = lane & 31 pairs) and V (wave 1: d = lane); other waves load the same words and ignore them
+    const float* ks_ = row + Hq * 64 + hk * 64;
+    kx1 = ks_[lane & 31]; kx2 = ks_[(lane & 31) + 32];
+    vx = row[(Hq + Hkv) * 64 + hk * 64 + lane];
+    const float* cs_row = inv_freq + (int64_t)min(pos, ctx_max - 1) * 64;  // [pos][cos 32 | sin 32] table
+    c0 = *(const float4*)(cs_row + 8 * lg); c1 = *(const float4*)(cs_row + 8 * lg + 4);
+    s0 = *(const float4*)(cs_row + 32 + 8 * lg); s1 = *(const float4*)(cs_row + 32 + 8 * lg + 4);
+    kcs = cs_row[lane & 31]; ksn = cs_row[32 + (lane & 31)];
+  }
+  // only tiles that hold valid keys are fetched (wave-uniform conditions around whole batches of loads)
+  if (wid < ntiles) load_tile(kfA, vfA, wid);
+  if (wid + DA_WAVES < ntiles) load_tile(kfB, vfB, wid + DA_WAVES);
+  if constexpr (FUSED) {
+#define ROPE_LO(x1, x2, c, s_) ((x1) * (c) - (x2) * (s_))
+#define ROPE_HI(x1, x2, c, s_) ((x2) * (c) + (x1) * (s_))
+    const uint32_t qm = lq < G ? 0xFFFFFFFFu : 0u;
+    qf[0] = make_uint4(pack2<DT>(ROPE_LO(a0.x, b0.x, c0.x, s0.x), ROPE_LO(a0.y, b0.y, c0.y, s0.y)) & qm,
+                       pack2<DT>(ROPE_LO(a0.z, b0.z, c0.z, s0.z), ROPE_LO(a0.w, b0.w, c0.w, s0.w)) & qm,
+                       pack2<DT>(ROPE_LO(a1.x, b1.x, c1.x, s1.x), ROPE_LO(a1.y, b1.y, c1.y, s1.y)) & qm,
+                       pack2<DT>(ROPE_LO(a1.z, b1.z, c1.z, s1.z), ROPE_LO(a1.w, b1.w, c1.w, s1.w)) & qm);
+    qf[1] = make_uint4(pack2<DT>(ROPE_HI(a0.x, b0.x, c0.x, s0.x), ROPE_HI(a0.y, b0.y, c0.y, s0.y)) & qm,
+                       pack2<DT>(ROPE_HI(a0.z, b0.z, c0.z, s0.z), ROPE_HI(a0.w, b0.w, c0.w, s0.w)) & qm,
+                       pack2<DT>(ROPE_HI(a1.x, b1.x, c1.x, s1.x), ROPE_HI(a1.y, b1.y, c1.y, s1.y)) & qm,
+                       pack2<DT>(ROPE_HI(a1.z, b1.z, c1.z, s1.z), ROPE_HI(a1.w, b1.w, c1.w, s1.w)) & qm);
+#undef ROPE_LO
+#undef ROPE_HI
+    if (wid == 0 && lane < 32) {
+      const uint16_t k1 = Elem16<DT>::from_f32(kx1 * kcs - kx2 * ksn), k2 = Elem16<DT>::from_f32(kx2 * kcs + kx1 * ksn);
+      s_newk[lane] = k1;
+      s_newk[lane + 32] = k2;
+      if (pos < ctx_max) {
+        Kb[(int64_t)pos * 64 + lane] = k1;
+        Kb[(int64_t)pos * 64 + lane + 32] = k2;
+      }
+    } else if (wid == 1) {
+      const uint16_t vv = Elem16<DT>::from_f32(vx);
+      s_newv[lane] = vv;
+      if (pos < ctx_max) Vb[(int64_t)lane * ctx_max + pos] = vv;
+    }
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint4 t = *(const uint4*)(q + (int64_t)b * ldq + (hk * G + min(lq, G - 1)) * 64 + (ks * 4 + lg) * 8);
+      const uint32_t qm = lq < G ? 0xFFFFFFFFu : 0u;
+      qf[ks] = make_uint4(t.x & qm, t.y & qm, t.z & qm, t.w & qm);
+    }
+  }
+
+  f32x4_t oacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) oacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float mrun = NEG_BIG, lrun = 0.f;
+  const float sc = scale * 1.4426950408889634f;
+
+  // (always_inline: called four times; as a real call the fragment arrays would live in scratch)
+  auto tile_step = [&](uint4 (&kf)[4][2], uint2 (&vf)[4][2][2], int t) __attribute__((always_inline)) {
+    const int j0 = t << 6;
+    if (fused && pos >= j0 && pos < j0 + 64 && pos < ctx_max) {
+      // this tile holds the new token: its K row / V column come from LDS (the global copies were stale when loaded)
+      const int rel = pos - j0;
+      const uint4 nk0 = *(const uint4*)(s_newk + lg * 8), nk1 = *(const uint4*)(s_newk + 32 + lg * 8);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const bool hit = (kt * 16 + lq) == rel;
+        // (component-wise: a ?: between two uint4 lvalues selects an address and drags the fragments into scratch)
+        const uint4 o0 = kf[kt][0], o1 = kf[kt][1];
+        kf[kt][0] = make_uint4(hit ? nk0.x : o0.x, hit ? nk0.y : o0.y, hit ? nk0.z : o0.z, hit ? nk0.w : o0.w);
+        kf[kt][1] = make_uint4(hit ? nk1.x : o1.x, hit ? nk1.y : o1.y, hit ? nk1.z : o1.z, hit ? nk1.w : o1.w);
+      }
+      const int e = rel & 3;
+      const uint32_t emask = (e & 1) ? 0xFFFF0000u : 0x0000FFFFu;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const uint32_t nv = (uint32_t)s_newv[dt * 16 + lq] << ((e & 1) * 16);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const bool hit = ((rel >> 2) == (8 * s2 + 4 * h + lg));
+            const uint2 v = vf[dt][s2][h];
+            const uint32_t x0 = (hit && e < 2) ? ((v.x & ~emask) | nv) : v.x;
+            const uint32_t x1 = (hit && e >= 2) ? ((v.y & ~emask) | nv) : v.y;
+            vf[dt][s2][h] = make_uint2(x0, x1);
+          }
       }
     }
     f32x4_t sacc[4];
@@ -405,14 +708,14 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(const uint16_t* q, int
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mnew = fmaxf(mrun, mx);
-    const float alpha = exp2f(mrun - mnew);
+    const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
     mrun = mnew;
     float ls = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = exp2f(sacc[kt][r] - mnew);
+        const float e = __builtin_amdgcn_exp2f(sacc[kt][r] - mnew);
         sacc[kt][r] = e;
         ls += e;
       }
@@ -432,6 +735,14 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(const uint16_t* q, int
       for (int s2 = 0; s2 < 2; ++s2)
         oacc[dt] = mfma_block<DT>(make_uint4(vf[dt][s2][0].x, vf[dt][s2][0].y, vf[dt][s2][1].x, vf[dt][s2][1].y), pf[s2], oacc[dt]);
     }
+  };
+
+  if (wid < ntiles) tile_step(kfA, vfA, wid);  // wave-uniform conditions
+  if (wid + DA_WAVES < ntiles) tile_step(kfB, vfB, wid + DA_WAVES);
+  for (int t0 = wid + 2 * DA_WAVES; t0 < ntiles; t0 += 2 * DA_WAVES) {  // contexts beyond 1024 keys: one round trip per pair
+    load_tiles(t0);
+    tile_step(kfA, vfA, t0);
+    if (t0 + DA_WAVES < ntiles) tile_step(kfB, vfB, t0 + DA_WAVES);
   }
   // ---- merge the waves (log-sum-exp)
   float l = lrun;
@@ -453,7 +764,7 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(const uint16_t* q, int
       float lt = 0.f, o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int w_ = 0; w_ < DA_WAVES; ++w_) {
-        const float ww = exp2f(s_m[w_][c] - mm);
+        const float ww = __builtin_amdgcn_exp2f(s_m[w_][c] - mm);
         lt += s_l[w_][c] * ww;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] += s_o[w_][d0 + r][c] * ww;
@@ -487,16 +798,40 @@ __device__ __forceinline__ BestKV better(BestKV a, BestKV b) { return (b.v > a.v
 
 constexpr int SV_PER = 32;  // values per thread -> V <= 8192
 
+constexpr int SC_CAP = 256;  // candidate pool of the threshold pass
+// lane l's value as a wave-uniform scalar (v_readlane_b32; l must be a constant after unrolling)
+__device__ __forceinline__ float lane_bcast(float x, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
+
 __global__ __launch_bounds__(256) void sample_kernel(const cv_sample_params p) {
   __shared__ float s_red[4];
   __shared__ BestKV s_best[4];
   __shared__ float s_candp[64];
   __shared__ int s_candi[64];
-  __shared__ float s_scan[256];
+  __shared__ __attribute__((aligned(16))) float s_scan[256];
+  __shared__ float s_cv[SC_CAP];
+  __shared__ int s_ci[SC_CAP];
+  __shared__ int s_cnt;
+  __shared__ float s_thr;
   __shared__ int s_flag[4];   // [0] need_fallback, [1] token, [2] done
   __shared__ float s_u2;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  if (p.finished[b] != 0) return;
+  // every scalar of the bookkeeping is fetched up front, in one batch with the logits (each used to be its own
+  // dependent round trip further down)
+  const int fin0 = p.finished[b];
+  const int step = p.step[b];
+  const int min_len_b = p.min_len[b];
+  const int n_em = p.n_emitted[b];
+  const int max_len_b = p.max_len[b];
+  // the last win_size emitted ids, one per lane (repetition check, utils/common.py:111-113)
+  const int widx = n_em - p.win_size + lane;
+  const int recent = p.out_tokens[(int64_t)b * p.out_ld + min(max(widx, 0), p.out_ld - 1)];
+  const bool recent_ok = lane < p.win_size && widx >= 0;
+  int forced_tok = -1;
+  if (p.forced) forced_tok = p.forced[(int64_t)b * p.forced_ld + min(n_em, p.forced_ld - 1)];
+  const int last_tok = p.out_tokens[(int64_t)b * p.out_ld + min(max(n_em - 1, 0), p.out_ld - 1)];
+  if (fin0 != 0) return;
   const float* lg = p.logits + (int64_t)b * p.ldl;
   const int V = p.V;
 
@@ -511,6 +846,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const cv_sample_params p) {
   }
   mx = wave_max(mx);
   if (lane == 0) s_red[wid] = mx;
+  if (tid == 0) s_cnt = 0;
   __syncthreads();
   mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
   __syncthreads();
@@ -525,43 +861,97 @@ __global__ __launch_bounds__(256) void sample_kernel(const cv_sample_params p) {
   __syncthreads();
   sum = s_red[0] + s_red[1] + s_red[2] + s_red[3];
   const float inv = 1.0f / sum;
+  float lmax = -1.f;
 #pragma unroll
-  for (int j = 0; j < SV_PER; ++j) v[j] *= inv;  // probabilities
+  for (int j = 0; j < SV_PER; ++j) {
+    v[j] *= inv;  // probabilities
+    lmax = fmaxf(lmax, (tid + 256 * j) < V ? v[j] : -1.f);
+  }
 
-  // ---- nucleus candidates: descending prob, stable (lower index first); take while cum < top_p and n < top_k
-  uint32_t taken = 0;
-  int ncand = 0;
-  float cum = 0.f;
+  // ---- nucleus candidates: descending prob, stable (lower index first); take while cum < top_p and n < top_k.
+  // Threshold pass: the top_k-th largest of the 256 per-thread maxima bounds the top_k-th largest probability from below,
+  // so every nucleus candidate is >= it; the few values above it are pooled in LDS and ordered by rank counting.  (The
+  // first version extracted the maxima one by one: top_k x (32-value scan + 12 dependent cross-lane steps + 2 barriers),
+  // 39 us per token.)  A pool overflow (near-constant logits) falls back to that loop.
   const int top_k = min(p.top_k, 64);
-  while (ncand < top_k && cum < p.top_p) {
-    BestKV best{-1.f, 0x7fffffff};
-#pragma unroll
-    for (int j = 0; j < SV_PER; ++j)
-      if (!((taken >> j) & 1u) && (tid + 256 * j) < V && v[j] > best.v) best = BestKV{v[j], tid + 256 * j};
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      BestKV other{__shfl_xor(best.v, o, 64), __shfl_xor(best.i, o, 64)};
-      best = better(best, other);
+  s_scan[tid] = lmax;
+  __syncthreads();
+  {
+    int rank = 0;
+#pragma unroll 8
+    for (int i = 0; i < 256; i += 4) {
+      const float4 o = *(const float4*)(s_scan + i);
+      rank += (o.x > lmax || (o.x == lmax && i + 0 < tid)) ? 1 : 0;
+      rank += (o.y > lmax || (o.y == lmax && i + 1 < tid)) ? 1 : 0;
+      rank += (o.z > lmax || (o.z == lmax && i + 2 < tid)) ? 1 : 0;
+      rank += (o.w > lmax || (o.w == lmax && i + 3 < tid)) ? 1 : 0;
     }
-    if (lane == 0) s_best[wid] = best;
-    __syncthreads();
-    best = better(better(s_best[0], s_best[1]), better(s_best[2], s_best[3]));
-    __syncthreads();
-    if ((best.i & 255) == tid) taken |= 1u << (best.i >> 8);
-    if (tid == 0) { s_candp[ncand] = best.v; s_candi[ncand] = best.i; }
-    cum += best.v;
-    ++ncand;
+    if (rank == top_k - 1) s_thr = lmax;
   }
   __syncthreads();
+  const float thr = s_thr;
+#pragma unroll
+  for (int j = 0; j < SV_PER; ++j) {
+    const int i = tid + 256 * j;
+    if (i < V && v[j] >= thr) {
+      const int slot = atomicAdd(&s_cnt, 1);
+      if (slot < SC_CAP) { s_cv[slot] = v[j]; s_ci[slot] = i; }
+    }
+  }
+  __syncthreads();
+  const int pool = s_cnt;
+  int ncand = 0;
+  float cum = 0.f;
+  if (pool <= SC_CAP) {
+    if (tid < pool) {
+      const BestKV mine{s_cv[tid], s_ci[tid]};
+      int rank = 0;
+      for (int i = 0; i < pool; ++i) {
+        const BestKV o{s_cv[i], s_ci[i]};
+        rank += (o.v > mine.v || (o.v == mine.v && o.i < mine.i)) ? 1 : 0;
+      }
+      if (rank < 64) { s_candp[rank] = mine.v; s_candi[rank] = mine.i; }
+    }
+    __syncthreads();
+    // sequential fp32 prefix in candidate order (the reference's accumulation order), on wave-uniform values
+    const int kmax = min(top_k, pool);
+    const float cp = s_candp[min(lane, max(kmax - 1, 0))];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      if (i >= kmax || cum >= p.top_p) break;
+      cum += lane_bcast(cp, i);
+      ++ncand;
+    }
+  } else {
+    uint32_t taken = 0;
+    while (ncand < top_k && cum < p.top_p) {
+      BestKV best{-1.f, 0x7fffffff};
+#pragma unroll
+      for (int j = 0; j < SV_PER; ++j)
+        if (!((taken >> j) & 1u) && (tid + 256 * j) < V && v[j] > best.v) best = BestKV{v[j], tid + 256 * j};
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        BestKV other{__shfl_xor(best.v, o, 64), __shfl_xor(best.i, o, 64)};
+        best = better(best, other);
+      }
+      if (lane == 0) s_best[wid] = best;
+      __syncthreads();
+      best = better(better(s_best[0], s_best[1]), better(s_best[2], s_best[3]));
+      __syncthreads();
+      if ((best.i & 255) == tid) taken |= 1u << (best.i >> 8);
+      if (tid == 0) { s_candp[ncand] = best.v; s_candi[ncand] = best.i; }
+      cum += best.v;
+      ++ncand;
+    }
+    __syncthreads();
+  }
 
   // ---- trials (llm.py:813-820): redraw while EOS is sampled before min_len
-  const int step = p.step[b];
-  const bool ignore_eos = step < p.min_len[b];
-  const int n_em = p.n_emitted[b];
+  const bool ignore_eos = step < min_len_b;
   int token = -1;
   int status = 0;
   for (int trial = 0;; ++trial) {
-    if (tid == 0) {
+    if (wid == 0) {
       float u1, u2;
       if (p.uniforms) {
         u1 = p.uniforms[((int64_t)b * (p.max_trials + 1) + trial) * 2];
@@ -572,22 +962,26 @@ __global__ __launch_bounds__(256) void sample_kernel(const cv_sample_params p) {
         u1 = u01(r.x);
         u2 = u01(r.y);
       }
-      // nucleus draw: inverse CDF over the candidate probabilities (renormalised)
+      // nucleus draw: inverse CDF over the candidate probabilities (renormalised); candidates live one per lane
+      const float cpl = s_candp[min(lane, max(ncand - 1, 0))];
+      const int cil = s_candi[min(lane, max(ncand - 1, 0))];
       const float target = u1 * cum;
       float c = 0.f;
       int pick = ncand - 1;
-      for (int i = 0; i < ncand; ++i) {
-        c += s_candp[i];
+#pragma unroll
+      for (int i = 0; i < 64; ++i) {
+        if (i >= ncand) break;
+        c += lane_bcast(cpl, i);
         if (c > target) { pick = i; break; }
       }
-      int tok = s_candi[pick];
+      const int tok = __shfl(cil, max(pick, 0), 64);
       // repetition check over the last win_size emitted tokens (utils/common.py:111-113)
-      int rep = 0;
-      const int w0 = max(0, n_em - p.win_size);
-      for (int i = w0; i < n_em; ++i) rep += (p.out_tokens[(int64_t)b * p.out_ld + i] == tok);
-      s_flag[0] = ((float)rep >= (float)p.win_size * p.tau_r) ? 1 : 0;
-      s_flag[1] = tok;
-      s_u2 = u2;
+      const int rep = __popcll(__ballot(recent_ok && recent == tok));
+      if (lane == 0) {
+        s_flag[0] = ((float)rep >= (float)p.win_size * p.tau_r) ? 1 : 0;
+        s_flag[1] = tok;
+        s_u2 = u2;
+      }
     }
     __syncthreads();
     if (s_flag[0]) {
@@ -636,7 +1030,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const cv_sample_params p) {
 
   // ---- bookkeeping (llm.py:866-874)
   if (p.forced) {
-    const int f = (n_em < p.forced_ld) ? p.forced[(int64_t)b * p.forced_ld + n_em] : -2;
+    const int f = (n_em < p.forced_ld) ? forced_tok : -2;
     if (f >= 0) { token = f; status = 1; }
     else if (f == -2) token = p.eos;  // forced list exhausted -> stop
   }
@@ -648,7 +1042,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const cv_sample_params p) {
   if (emit && n_em >= p.out_ld) { emit = false; fin = 2; }
   // next-step input embedding.  Emitted id -> its embedding; skipped id (> EOS, llm.py:869-870 `continue`) -> the
   // previous input again = embedding of the last emitted id (the residual stream has overwritten x meanwhile).
-  int next_in = emit ? token : ((!fin && n_em > 0) ? p.out_tokens[(int64_t)b * p.out_ld + n_em - 1] : -1);
+  int next_in = emit ? token : ((!fin && n_em > 0) ? last_tok : -1);
   if (next_in >= 0) {
     const float* e = p.emb_table + (int64_t)next_in * p.emb_dim;
     for (int i = tid; i < p.emb_dim; i += 256) p.x[(int64_t)b * p.ldx + i] = e[i];
@@ -660,7 +1054,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const cv_sample_params p) {
     }
     p.step[b] = step + 1;
     p.pos[b] += 1;
-    if (!fin && step + 1 >= p.max_len[b]) fin = 2;
+    if (!fin && step + 1 >= max_len_b) fin = 2;
     if (fin) p.finished[b] = fin;
   }
 }
@@ -698,38 +1092,71 @@ extern "C" int cv_skinny_gemm(const cv_skinny_params* pp, void* stream) {
   if (norm) {
     if (!p.nx || (p.K & 63) || p.K > 1024 || (p.ldnx & 3) || p.nx_out == p.nx) return CV_ERR_ARG;
     if (p.n_nslab > 0 && (!p.nslabs || (p.ld_nslab & 3) || (p.nslab_stride & 3))) return CV_ERR_ARG;
+    if (p.n_nslab != 0 && p.n_nslab != 1 && p.n_nslab != 2 && p.n_nslab != 4) return CV_ERR_ARG;
   }
   if (p.ksplit <= 0) p.ksplit = 1;
   const int ntiles = (p.N + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
   const size_t img = norm ? (size_t)(p.K >> 5) * 1024 : 0;
-  if (norm && p.n_nslab > 4) return CV_ERR_ARG;
-  const int nm = !norm ? 0 : (p.n_nslab > 0 ? 2 : 1);
+  const int nm = !norm ? 0 : 1 + p.n_nslab;
   const int tpr = p.M <= 4 ? 64 : (p.M <= 8 ? 32 : 16);
-#define SK_LAUNCH(TPW_, NM_, TPR_) \
-  DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, TPW_, NM_, TPR_>), grid, dim3(256), lds, st, p))
-#define SK_NORM(TPW_)                                                       \
-  do {                                                                      \
-    if (nm == 0) { SK_LAUNCH(TPW_, 0, 16); }                                \
-    else if (nm == 1) {                                                     \
-      if (tpr == 64) { SK_LAUNCH(TPW_, 1, 64); } else if (tpr == 32) { SK_LAUNCH(TPW_, 1, 32); } else { SK_LAUNCH(TPW_, 1, 16); } \
-    } else {                                                                \
-      if (tpr == 64) { SK_LAUNCH(TPW_, 2, 64); } else if (tpr == 32) { SK_LAUNCH(TPW_, 2, 32); } else { SK_LAUNCH(TPW_, 2, 16); } \
-    }                                                                       \
-  } while (0)
+  const int tpw = p.mode == 2 ? 2 : 1;
   if (p.mode == 2) {
     if (p.ksplit != 1 || (ntiles & 1) || !p.out_act || (p.ldoa & 3)) return CV_ERR_ARG;
-    dim3 grid(ntiles / 2, 1);
-    const size_t lds = 4 * 2 * 64 * 4 * sizeof(float) + img;
-    SK_NORM(2);
   } else {
     if (!p.out_f32) return CV_ERR_ARG;
     if (p.mode == 1 && p.ksplit != 1) return CV_ERR_ARG;
-    dim3 grid(ntiles, p.ksplit);
-    const size_t lds = 4 * 1 * 64 * 4 * sizeof(float) + img;
+  }
+  // k-steps one wave covers: the streaming kernel takes them as one batch of U fragment loads
+  const int per_wave = ((((p.K >> 5) + p.ksplit - 1) / p.ksplit) + 3) >> 2;
+  const int ngroups = ntiles / tpw;
+  if (per_wave > 16 || (tpw == 2 && per_wave > 8)) {
+    if (norm) return CV_ERR_UNSUPPORTED;  // cannot happen: the prologue needs K <= 1024
+    dim3 grid(ngroups, p.ksplit);
+    const size_t lds = 4 * tpw * 64 * 4 * sizeof(float);
+    if (tpw == 2) { DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, 2, 0, 16, 8>), grid, dim3(256), lds, st, p)); }
+    else { DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, 1, 0, 16, 8>), grid, dim3(256), lds, st, p)); }
+    CV_CHECK_LAUNCH();
+    return CV_OK;
+  }
+  int gx = ngroups;
+  if (p.max_wgs > 0) gx = std::min(ngroups, std::max(1, p.max_wgs / p.ksplit));
+  dim3 grid(gx, p.ksplit);
+  const bool loop = gx < ngroups;
+  const size_t lds = (loop ? 2 : 1) * 4 * tpw * 64 * 4 * sizeof(float) + img;
+  // every wave's K slice is exactly 7 k-steps (K = 896 * ksplit): single-shot launches use the clamp-free U = 7 form
+  const bool exact7 = !loop && per_wave == 7 && ((p.K >> 5) == 28 * p.ksplit);
+#define SK_LAUNCH7(TPW_, NM_, TPR_) \
+  DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, TPW_, NM_, TPR_, 7>), grid, dim3(256), lds, st, p))
+#define SK_LAUNCH(TPW_, NM_, TPR_, U_)                                                                                          \
+  do {                                                                                                                          \
+    if (loop) { DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_stream_kernel<DT, TPW_, NM_, TPR_, U_, true>), grid, dim3(256), lds, st, p)); } \
+    else { DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, TPW_, NM_, TPR_, U_>), grid, dim3(256), lds, st, p)); }                   \
+  } while (0)
+#define SK_TPR(TPW_, NM_)                                                                                                  \
+  do {                                                                                                                     \
+    if (tpr == 64) { SK_LAUNCH(TPW_, NM_, 64, 8); }                                                                        \
+    else if (tpr == 32) { if (exact7) { SK_LAUNCH7(TPW_, NM_, 32); } else { SK_LAUNCH(TPW_, NM_, 32, 8); } }               \
+    else { SK_LAUNCH(TPW_, NM_, 16, 8); }                                                                                  \
+  } while (0)
+#define SK_NORM(TPW_)                          \
+  do {                                         \
+    if (nm == 1) { SK_TPR(TPW_, 1); }          \
+    else if (nm == 2) { SK_TPR(TPW_, 2); }     \
+    else if (nm == 3) { SK_TPR(TPW_, 3); }     \
+    else { SK_TPR(TPW_, 5); }                  \
+  } while (0)
+  if (tpw == 2) {
+    if (nm == 0) { SK_LAUNCH(2, 0, 16, 8); } else { SK_NORM(2); }
+  } else if (nm == 0) {
+    if (exact7) { SK_LAUNCH7(1, 0, 16); }
+    else if (per_wave <= 8) { SK_LAUNCH(1, 0, 16, 8); } else if (per_wave <= 12) { SK_LAUNCH(1, 0, 16, 12); } else { SK_LAUNCH(1, 0, 16, 16); }
+  } else {
     SK_NORM(1);
   }
 #undef SK_NORM
+#undef SK_TPR
+#undef SK_LAUNCH7
 #undef SK_LAUNCH
   CV_CHECK_LAUNCH();
   return CV_OK;
@@ -768,9 +1195,15 @@ extern "C" int cv_decode_attention(const void* q, int32_t ldq, const void* kcach
   if (qkv && (!inv_freq || ldqkv < (Hq + 2 * Hkv) * 64)) return CV_ERR_ARG;
   if ((ldo & 3) || (ctx_max & 63)) return CV_ERR_ARG;
   dim3 grid(Hkv, B);
-  DISPATCH_16(dtype, hipLaunchKernelGGL(decode_attn_kernel<DT>, grid, dim3(512), 0, (hipStream_t)stream, (const uint16_t*)q, ldq,
-                                        (uint16_t*)kcache, (uint16_t*)vtcache, ctx_len, ctx_add, (uint16_t*)out, ldo, Hq, Hkv,
-                                        ctx_max, scale, qkv, ldqkv, inv_freq));
+  if (qkv) {
+    DISPATCH_16(dtype, hipLaunchKernelGGL((decode_attn_kernel<DT, true>), grid, dim3(512), 0, (hipStream_t)stream, (const uint16_t*)q, ldq,
+                                          (uint16_t*)kcache, (uint16_t*)vtcache, ctx_len, ctx_add, (uint16_t*)out, ldo, Hq, Hkv,
+                                          ctx_max, scale, qkv, ldqkv, inv_freq));
+  } else {
+    DISPATCH_16(dtype, hipLaunchKernelGGL((decode_attn_kernel<DT, false>), grid, dim3(512), 0, (hipStream_t)stream, (const uint16_t*)q, ldq,
+                                          (uint16_t*)kcache, (uint16_t*)vtcache, ctx_len, ctx_add, (uint16_t*)out, ldo, Hq, Hkv,
+                                          ctx_max, scale, qkv, ldqkv, inv_freq));
+  }
   CV_CHECK_LAUNCH();
   return CV_OK;
 }

@@ -14,6 +14,7 @@ Design (MI355X-first, not the reference's 4-graphs-per-layer path, llm/qwen2_5.p
 Batching: B <= 16 sequences per step share every weight read (the reference is batch-1).
 """
 import math
+import os
 from typing import Dict, Generator, List, Optional
 
 import torch
@@ -30,7 +31,7 @@ def _round_up(x, m):
 
 
 class Qwen2LM:
-    DOWN_KSPLIT = 4
+    DOWN_KSPLIT = int(os.environ.get("CV_DOWN_KSPLIT", "4"))  # down-projection K slices (1: in-place `x +=`, no slabs)
 
     def __init__(self, cfg: Optional[LlmConfig] = None, dtype: torch.dtype = torch.bfloat16, device: str = "cuda",
                  max_batch: int = 8, ctx_max: int = 1024, max_out: int = 2048, top_p: float = 0.8, top_k: int = 25,
@@ -44,6 +45,10 @@ class Qwen2LM:
         self.sos_eos, self.task_id = 0, 1
         self.fp16 = False
         self.seed = 0
+        # > 0: cap the weight-streaming kernels at about this many workgroups, each walking several tile groups with the next
+        # group prefetched (cv_skinny_params.max_wgs).  Measured slower than single-shot workgroups at three per CU on the
+        # 104-CU share tts_batches gives the decode loop (tools/llm_kernel_bench.py), so it stays off.
+        self.cu_budget = 0
         self.use_graph = True
         self._loaded = False
         self._graphs: Dict[int, ops.Graph] = {}
@@ -116,7 +121,8 @@ class Qwen2LM:
     def _head_and_sample(self, B, use_forced, use_uniforms):
         cfg, st = self.cfg, self.st
         H = cfg.hidden_size
-        ops.skinny_gemm(st["xn"], self.p_dec, B, cfg.out_vocab, H, bias=self.dec_b, out_f32=st["logits"], ldo=self.Vpad)
+        ops.skinny_gemm(st["xn"], self.p_dec, B, cfg.out_vocab, H, bias=self.dec_b, out_f32=st["logits"], ldo=self.Vpad,
+                        max_wgs=2 * self.cu_budget)
         p = L.SampleParams()
         p.logits, p.ldl, p.V, p.B = st["logits"].data_ptr(), self.Vpad, cfg.out_vocab, B
         p.eos, p.top_k, p.top_p, p.win_size, p.tau_r = cfg.speech_token_size, self.top_k, self.top_p, self.win_size, self.tau_r
@@ -138,8 +144,24 @@ class Qwen2LM:
         qkv_dim = cfg.q_dim + 2 * cfg.kv_dim
         KS = self.DOWN_KSPLIT
         scale = 1.0 / math.sqrt(cfg.head_dim)
+        mw = self.cu_budget
         # residual stream ping-pongs between x (even layers) and x2 (odd): the fused prologue of the QKV kernel reads
         # cur (+ the previous layer's down-proj slabs) and its workgroup (0,0) writes the summed residual to nxt
+        if KS == 1:
+            # the residual row is updated in place by the two `out +=` projections; every norm prologue reads it directly
+            x = st["x"]
+            for li, lay in enumerate(self.layers):
+                ops.skinny_gemm(st["xn"], lay["p_qkv"], B, qkv_dim, H, bias=lay["bqkv"], out_f32=st["qkv"], ldo=qkv_dim,
+                                norm=dict(x=x, gamma=lay["g_in"], eps=cfg.rms_eps))
+                ops.decode_attention(st["q"], self.kcache[li], self.vtcache[li], st["pos"], 1, st["ao"], B, cfg.num_heads,
+                                     cfg.num_kv_heads, self.ctx_max, scale, qkv=st["qkv"], inv_freq=self.rope_table)
+                ops.skinny_gemm(st["ao"], lay["p_o"], B, H, cfg.q_dim, mode=1, out_f32=x, ldo=H)
+                ops.skinny_gemm(st["xn"], lay["p_gu"], B, 2 * I, H, mode=2, out_act=st["h"], ldoa=I,
+                                norm=dict(x=x, gamma=lay["g_post"], eps=cfg.rms_eps))
+                ops.skinny_gemm(st["h"], lay["p_down"], B, H, I, mode=1, out_f32=x, ldo=H)
+            ops.rmsnorm_reduce(x, self.g_final, cfg.rms_eps, st["xn"], B)
+            self._head_and_sample(B, use_forced, use_uniforms)
+            return
         cur, nxt = st["x"], st["x2"]
         for li, lay in enumerate(self.layers):
             nrm = dict(x=cur, gamma=lay["g_in"], eps=cfg.rms_eps, x_out=nxt)
@@ -150,8 +172,8 @@ class Qwen2LM:
                                  cfg.num_kv_heads, self.ctx_max, scale, qkv=st["qkv"], inv_freq=self.rope_table)
             ops.skinny_gemm(st["ao"], lay["p_o"], B, H, cfg.q_dim, mode=1, out_f32=nxt, ldo=H)
             ops.skinny_gemm(st["xn"], lay["p_gu"], B, 2 * I, H, mode=2, out_act=st["h"], ldoa=I,
-                            norm=dict(x=nxt, gamma=lay["g_post"], eps=cfg.rms_eps))
-            ops.skinny_gemm(st["h"], lay["p_down"], B, H, I, ksplit=KS, out_f32=st["slabs"], ldo=H, slab_stride=16 * H)
+                            norm=dict(x=nxt, gamma=lay["g_post"], eps=cfg.rms_eps), max_wgs=mw)
+            ops.skinny_gemm(st["h"], lay["p_down"], B, H, I, ksplit=KS, out_f32=st["slabs"], ldo=H, slab_stride=16 * H, max_wgs=mw)
             cur, nxt = nxt, cur
         ops.rmsnorm_reduce(cur, self.g_final, cfg.rms_eps, st["xn"], B, slabs=st["slabs"], nslab=KS, slab_stride=16 * H, ld_slab=H)
         self._head_and_sample(B, use_forced, use_uniforms)
@@ -160,7 +182,7 @@ class Qwen2LM:
         if not self.use_graph:
             self._decode_step(B, use_forced, use_uniforms)
             return
-        key = (B, use_forced, use_uniforms, self.seed)
+        key = (B, use_forced, use_uniforms, self.seed, self.cu_budget)
         g = self._graphs.get(key)
         if g is None:
             g = ops.Graph().capture(lambda: self._decode_step(B, use_forced, use_uniforms))

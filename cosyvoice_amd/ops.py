@@ -254,7 +254,7 @@ def pack_skinny(W, interleave=False):
 
 
 def skinny_gemm(A, Wp, M, N, K, *, bias=None, ksplit=1, mode=0, out_f32=None, ldo=0, slab_stride=0, out_act=None, ldoa=0,
-                norm=None):
+                norm=None, max_wgs=0):
     """norm = dict(x=, gamma=, eps=, x_out=None, slabs=None, nslab=0, slab_stride=0, ld_slab=0): fused RMSNorm prologue
     (A is then unused; pass any 16-bit tensor for the dtype)."""
     _req_cuda(A, Wp, bias, out_f32, out_act)
@@ -272,6 +272,7 @@ def skinny_gemm(A, Wp, M, N, K, *, bias=None, ksplit=1, mode=0, out_f32=None, ld
         p.nslab_stride, p.ld_nslab = norm.get("slab_stride", 0), norm.get("ld_slab", 0)
         p.ngamma, p.neps = norm["gamma"].data_ptr(), norm["eps"]
         p.nx_out = L.ptr(norm.get("x_out"))
+    p.max_wgs = max_wgs
     L.check(L.lib().cv_skinny_gemm(C.byref(p), L.stream_ptr()), "cv_skinny_gemm")
 
 

@@ -193,6 +193,9 @@ typedef struct cv_skinny_params {
   const float* nslabs; int32_t n_nslab; int64_t nslab_stride; int32_t ld_nslab;
   const float* ngamma; float neps;
   float* nx_out;
+  /* > 0: cap on the workgroups launched (x ksplit slices); each then walks several tile groups with the next group's
+     weights prefetched.  Set to about 2 x the CUs the calling stream owns; 0 = one workgroup per tile group. */
+  int32_t max_wgs;
 } cv_skinny_params;
 int cv_skinny_gemm(const cv_skinny_params* p, void* stream);
 /* W [N][K] row-major 16-bit (device) -> packed (device), N padded up to a multiple of 16 with zeros.

@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M,N,K,ksplit", [(1, 896, 896, 1), (8, 1152, 896, 1), (8, 896, 4864, 4), (3, 6564, 896, 1), (16, 256, 512, 2)])
+@pytest.mark.parametrize("M,N,K,ksplit", [(1, 896, 896, 1), (8, 1152, 896, 1), (8, 896, 4864, 4), (3, 6564, 896, 1), (16, 256, 512, 2),
+                                          (8, 896, 4864, 2), (4, 320, 4864, 1)])  # last: K slice beyond 16 k-steps per wave
 def test_skinny_gemm_modes(dt, M, N, K, ksplit):
     from cosyvoice_amd import ops
     torch.manual_seed(0)
@@ -40,6 +41,17 @@ def test_skinny_gemm_modes(dt, M, N, K, ksplit):
         ops.skinny_gemm(A, Wp, M, N, K, mode=1, out_f32=x, ldo=Np)
         torch.cuda.synchronize()
         assert (x[:M, :N] - (x0[:M, :N] + ref)).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+    # capped grids (workgroups walk several tile groups, next group's weights prefetched) are bit-identical
+    for cap in (7 * ksplit, 2 * ksplit, 40):
+        s2 = torch.zeros_like(slabs)
+        ops.skinny_gemm(A, Wp, M, N, K, bias=bias, ksplit=ksplit, out_f32=s2, ldo=Np, slab_stride=16 * Np, max_wgs=cap)
+        torch.cuda.synchronize()
+        assert torch.equal(s2, slabs), cap
+        if ksplit == 1:
+            x2 = x0.clone()
+            ops.skinny_gemm(A, Wp, M, N, K, mode=1, out_f32=x2, ldo=Np, max_wgs=cap)
+            torch.cuda.synchronize()
+            assert torch.equal(x2, x), cap
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
@@ -59,6 +71,11 @@ def test_skinny_swiglu(dt):
     ref = torch.nn.functional.silu(A[:M].float() @ g.float().t()) * (A[:M].float() @ u.float().t())
     tol = 3e-2 if dt == torch.bfloat16 else 4e-3
     assert (h[:M].float() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+    for cap in (3, 96, 192):
+        h2 = torch.zeros_like(h)
+        ops.skinny_gemm(A, Wp, M, 2 * I, K, mode=2, out_act=h2, ldoa=I, max_wgs=cap)
+        torch.cuda.synchronize()
+        assert torch.equal(h2, h), cap
 
 
 def test_rmsnorm_reduce_and_rope_decode_attention():
