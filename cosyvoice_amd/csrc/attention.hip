@@ -23,7 +23,20 @@ __global__ __launch_bounds__(256) void attn_kernel(const cv_attn_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lq = lane & 15, lg = lane >> 4;
-  const int kfrag0 = (lq << 7) + ((lg ^ ((lq >> 1) & 7)) << 4), kfrag1 = (lq << 7) + (((4 + lg) ^ ((lq >> 1) & 7)) << 4);
+  // Key order inside a 64-key tile: row lq of S^T sub-tile kt is key krow(kt) = (kt>>1)*32 + (lq>>2)*8 + (kt&1)*4 + (lq&3), so
+  // that the scores a lane holds for sub-tiles 2s and 2s+1 are 8 CONSECUTIVE keys (s*32 + lg*8 ..+7): P^T is then already
+  // in MFMA B-operand order and the V^T fragment is one 16-byte LDS read instead of two 8-byte ones.  The K image keeps
+  // its 128-byte rows; the XOR swizzle is keyed on ((row>>1)&1) | ((row>>2)&6) so the 8 same-parity rows a 16-lane read
+  // pass touches (0,2,8,10,16,18,24,26 + const) land in 8 different 16-byte slots.
+  const int krow_lo = ((lq >> 2) << 3) + (lq & 3);
+  auto kswz = [](int row) { return ((row >> 1) & 1) | ((row >> 2) & 6); };
+  int kfrag0[4], kfrag1[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    const int row = ((kt >> 1) << 5) + ((kt & 1) << 2) + krow_lo;
+    kfrag0[kt] = (row << 7) + ((lg ^ kswz(row)) << 4);
+    kfrag1[kt] = (row << 7) + (((4 + lg) ^ kswz(row)) << 4);
+  }
   const int b = blockIdx.z, h = blockIdx.y;
   const int hk = h / (p.H / p.Hkv);
   const int q_wg = blockIdx.x * 128;
@@ -82,7 +95,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const cv_attn_params p) {
       const int r = c >> 3, dc = c & 7;
       const int kr = r, kdc = dc;
       const uint32_t km = (tile_j0 + kr < klen) ? 0xFFFFFFFFu : 0u;
-      *(uint4*)(sk + (kr << 7) + ((kdc ^ ((kr >> 1) & 7)) << 4)) =  // row-major, XOR-swizzled chunk slot (see gemm.hip)
+      *(uint4*)(sk + (kr << 7) + ((kdc ^ kswz(kr)) << 4)) =  // row-major, XOR-swizzled chunk slot
           make_uint4(rk[i].x & km, rk[i].y & km, rk[i].z & km, rk[i].w & km);
       // zero every key >= klen of the V^T chunk (0 * garbage must not become NaN)
       const int nvalid = klen - (tile_j0 + dc * 8);
@@ -122,8 +135,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const cv_attn_params p) {
     f32x4_t sacc[4][2];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      const uint4 k0 = *(const uint4*)(sk + (kt << 11) + kfrag0);
-      const uint4 k1 = *(const uint4*)(sk + (kt << 11) + kfrag1);
+      const uint4 k0 = *(const uint4*)(sk + kfrag0[kt]);
+      const uint4 k1 = *(const uint4*)(sk + kfrag1[kt]);
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
         f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -154,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const cv_attn_params p) {
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int j = j0 + kt * 16 + 4 * lg + r;
+            const int j = j0 + ((kt >> 1) << 5) + (lg << 3) + ((kt & 1) << 2) + r;
             float v = fmaf(sacc[kt][qt][r], sc, brow[min(j, p.Tk - 1)] * 1.4426950408889634f);
             v = (j < jlim) ? v : NEG_BIG;
             sacc[kt][qt][r] = v;
@@ -166,14 +179,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const cv_attn_params p) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = exp2f(sacc[kt][qt][r] - mnew);
+          for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = __builtin_amdgcn_exp2f(sacc[kt][qt][r] - mnew);
       } else {
         if (!tile_full) {
 #pragma unroll
           for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int j = j0 + kt * 16 + 4 * lg + r;
+              const int j = j0 + ((kt >> 1) << 5) + (lg << 3) + ((kt & 1) << 2) + r;
               sacc[kt][qt][r] = (j < jlim) ? sacc[kt][qt][r] : NEG_BIG;
             }
         }
@@ -187,19 +200,23 @@ __global__ __launch_bounds__(256) void attn_kernel(const cv_attn_params p) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = exp2f(fmaf(sacc[kt][qt][r], sc, -mnew));
+          for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = __builtin_amdgcn_exp2f(fmaf(sacc[kt][qt][r], sc, -mnew));
       }
-      const float alpha = exp2f(mrun[qt] - mnew);
+      // v_exp_f32 directly (exp2f's denormal handling costs four more VALU per element; a flushed 2^-127 is 0 here anyway)
+      const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+      const bool same_max = __all(mnew == mrun[qt]);  // running max unchanged for every query of the wave: alpha == 1
       mrun[qt] = mnew;
       float ls = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) ls += (sacc[kt][qt][0] + sacc[kt][qt][1]) + (sacc[kt][qt][2] + sacc[kt][qt][3]);
       lrun[qt] = lrun[qt] * alpha + ls;
+      if (!same_max) {
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        oacc[dt][qt][0] *= alpha; oacc[dt][qt][1] *= alpha; oacc[dt][qt][2] *= alpha; oacc[dt][qt][3] *= alpha;
+        for (int dt = 0; dt < 4; ++dt) {
+          oacc[dt][qt][0] *= alpha; oacc[dt][qt][1] *= alpha; oacc[dt][qt][2] *= alpha; oacc[dt][qt][3] *= alpha;
+        }
       }
-      // P^T fragments: k-step s2 covers key tiles 2*s2 (elements 0..3) and 2*s2+1 (elements 4..7)
+      // P^T fragments: k-step s2 = sub-tiles 2*s2 (elements 0..3) and 2*s2+1 (elements 4..7) = keys s2*32 + lg*8 ..+7
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         uint4 f;
@@ -214,12 +231,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const cv_attn_params p) {
     // ---- O^T += V^T . P^T
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      const char* vrow = sv + (dt * 16 + lq) * VT_PITCH + lg * 8;
+      const char* vrow = sv + (dt * 16 + lq) * VT_PITCH + lg * 16;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const uint2 lo = *(const uint2*)(vrow + s2 * 64);
-        const uint2 hi = *(const uint2*)(vrow + s2 * 64 + 32);
-        const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        const uint4 vf = *(const uint4*)(vrow + s2 * 64);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = mfma_block<DT>(vf, pf[qt][s2], oacc[dt][qt]);
       }
