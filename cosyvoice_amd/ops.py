@@ -1,5 +1,6 @@
 """Thin tensor-level wrappers over the C ABI (device pointers out of torch tensors; torch is plumbing only)."""
 import ctypes as C
+import sys
 
 import torch
 
@@ -212,8 +213,9 @@ class Graph:
         return L.lib().cv_graph_num_launches(self.handle)
 
     def __del__(self):
+        # not at interpreter shutdown: the HIP runtime (and a profiler attached to it) may already be finalising
         try:
-            if self.handle:
+            if self.handle and not sys.is_finalizing():
                 L.lib().cv_graph_destroy(self.handle)
         except Exception:
             pass

@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from cosyvoice_amd import ops
 B, H, T = 16, 8, 1000
 dt = torch.float16; dev = 'cuda'

@@ -1,7 +1,7 @@
 """Does a CU-masked stream (hipExtStreamCreateWithCUMask) constrain hipGraph replays?  LLM decode alone on masks of
 256 / 128 / 64 CUs, then flow+HiFT on the complementary mask concurrently."""
 import ctypes as C, sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import bench as B
 from cosyvoice_amd.config import FlowConfig, HiftConfig, LlmConfig
 from cosyvoice_amd.flow import CausalMaskedDiffWithXvec

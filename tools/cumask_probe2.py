@@ -2,7 +2,7 @@
 mask (cumask_probe.py), direct launches honour it: here flow+HiFT run as direct launches (use_graph=False) on a stream
 masked to a subset of CUs from a second host thread, while the LLM graph replays run unmasked at high priority."""
 import ctypes as C, sys, time, threading, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import bench as B
 from cosyvoice_amd.config import FlowConfig, HiftConfig, LlmConfig
 from cosyvoice_amd.flow import CausalMaskedDiffWithXvec

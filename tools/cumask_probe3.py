@@ -1,7 +1,7 @@
 """LLM decode and flow+HiFT on DISJOINT CU sets: both replayed launch by launch (cv_graph_launch_direct) on CU-masked
 streams, the flow side from a second host thread.  k = CU slots per XCD given to the LLM."""
 import sys, time, threading, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import bench as B
 from cosyvoice_amd import ops
 from cosyvoice_amd.config import FlowConfig, HiftConfig, LlmConfig

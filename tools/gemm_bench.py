@@ -1,6 +1,6 @@
 """Micro-benchmark of cv_gemm on the flow/HiFT/prefill shapes (events on the launch stream, interleaved rounds)."""
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from cosyvoice_amd import ops
 
 def bench(fn, n=30):

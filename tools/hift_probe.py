@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from cosyvoice_amd.config import HiftConfig
 from cosyvoice_amd.weights import hift_state_dict
 from cosyvoice_amd.hift import HiFTGenerator

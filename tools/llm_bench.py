@@ -1,7 +1,7 @@
 """LLM stage alone (C4 shape: batch 8, prefill 282, 250 forced tokens): all CUs (hipGraph replays) and on the CU share the
 pipeline gives it (direct launches on a masked stream).  Usage: python tools/llm_bench.py [slots_per_xcd ...]"""
 import sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import bench as B
 from cosyvoice_amd import ops
 from cosyvoice_amd.config import FlowConfig, LlmConfig

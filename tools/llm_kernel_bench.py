@@ -3,7 +3,7 @@ weights, so the stream stays HBM-cold as in the real step), replayed back to bac
 rocprofv3's per-kernel durations carry a ~3 us/kernel profiler floor on this stack (tools/ubench/floor*.hip) and cannot
 rank kernels this short."""
 import math, sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import bench as B
 from cosyvoice_amd import ops
 from cosyvoice_amd.config import FlowConfig, LlmConfig

@@ -1,6 +1,6 @@
 """Does LLM decode (side stream) overlap flow+HiFT (main stream)?  Times the phases alone and together."""
 import sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import bench as B
 from cosyvoice_amd.config import FlowConfig, HiftConfig, LlmConfig
 from cosyvoice_amd.flow import CausalMaskedDiffWithXvec

@@ -1,7 +1,7 @@
 """Runs ONLY the roofline kernel of bench.py (decode gate/up skinny GEMM, B=8, all 24 layers' packed weights, 5 sweeps)
 so that rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes give its HBM traffic per launch."""
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from cosyvoice_amd import ops
 H, I, B, L = 896, 4864, 8, 24
 dev = 'cuda'
