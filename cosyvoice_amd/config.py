@@ -155,3 +155,36 @@ class LlmConfig:
 
 
 __all__ = ["HiftConfig", "FlowConfig", "LlmConfig", "replace", "field"]
+
+
+@dataclass(frozen=True)
+class BigVGANConfig:
+    # /root/reference/cosyvoice/BigVGAN/bigvgan.py:257-276 (ctor defaults); encoder1 / encoder2 are injected modules there and
+    # stay injected here (None = tokens go straight to encoder_proj)
+    vocab_size: int = 6561
+    input_size: int = 512
+    output_size: int = 1024
+    mel_bin: int = 80
+    upsample_rates: Tuple[int, ...] = (4, 4, 4, 4, 2, 2)
+    upsample_kernel_sizes: Tuple[int, ...] = (8, 8, 4, 4, 4, 4)
+    upsample_initial_channel: int = 1536
+    resblock_kernel_sizes: Tuple[int, ...] = (3, 7, 11)
+    resblock_dilation_sizes: Tuple[Tuple[int, ...], ...] = ((1, 3, 5), (1, 3, 5), (1, 3, 5))
+    speaker_embedding_dim: int = 512
+    cond_in_each_up_layer: bool = True
+
+    @property
+    def total_upsample(self) -> int:
+        u = 1
+        for r in self.upsample_rates:
+            u *= r
+        return u
+
+    @staticmethod
+    def full() -> "BigVGANConfig":
+        return BigVGANConfig()
+
+    @staticmethod
+    def tiny() -> "BigVGANConfig":
+        return BigVGANConfig(vocab_size=64, input_size=32, output_size=48, upsample_rates=(4, 2), upsample_kernel_sizes=(8, 4),
+                             upsample_initial_channel=64, speaker_embedding_dim=16)

@@ -295,3 +295,41 @@ def fold_weight_norm(sd: Dict[str, torch.Tensor], name: str) -> torch.Tensor:
     v, g = sd[f"{name}.weight_v"], sd[f"{name}.weight_g"]
     nrm = v.reshape(v.shape[0], -1).norm(dim=1).reshape(g.shape)
     return v * (g / nrm)
+
+
+# --------------------------------------------------------------------------- BigVGAN
+def bigvgan_specs(cfg) -> List[Spec]:
+    """Keys of the reference's BigVGAN module tree (BigVGAN/bigvgan.py:257-382) for encoder1 = encoder2 = None."""
+    s: List[Spec] = []
+    s.append(("input_embedding.weight", (cfg.vocab_size, cfg.input_size), "normal", 1.0))
+    _linear(s, "encoder_proj", cfg.output_size, cfg.input_size)
+    c0 = cfg.upsample_initial_channel
+    _linear(s, "mel_proj", cfg.mel_bin, c0)
+    _wn_conv(s, "conv_pre", c0, cfg.output_size, 7, 1.0 / math.sqrt(cfg.output_size * 7))
+    sd = cfg.speaker_embedding_dim
+    s.append(("cond_layer.weight", (c0, sd, 1), "normal", 0.5 / math.sqrt(sd)))
+    s.append(("cond_layer.bias", (c0,), "normal", 0.02))
+    nk = len(cfg.resblock_kernel_sizes)
+    ch = c0
+    for i, (u, k) in enumerate(zip(cfg.upsample_rates, cfg.upsample_kernel_sizes)):
+        ch = c0 // 2 ** (i + 1)
+        _wn_conv(s, f"ups.{i}.0", ch, c0 // 2 ** i, k, 1.0 / math.sqrt(c0 // 2 ** i * k / u), transpose=True)
+        if cfg.cond_in_each_up_layer:
+            s.append((f"conds.{i}.weight", (ch, sd, 1), "normal", 0.5 / math.sqrt(sd)))
+            s.append((f"conds.{i}.bias", (ch,), "normal", 0.02))
+        for j, (k2, dils) in enumerate(zip(cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes)):
+            name = f"resblocks.{i * nk + j}"
+            for d in range(len(dils)):
+                _wn_conv(s, f"{name}.convs1.{d}", ch, ch, k2, 0.5 / math.sqrt(ch * k2))
+                _wn_conv(s, f"{name}.convs2.{d}", ch, ch, k2, 0.5 / math.sqrt(ch * k2))
+            for m in range(2 * len(dils)):
+                s.append((f"{name}.activations.{m}.act.alpha", (ch,), "normal", 0.3))   # log-scale parameters
+                s.append((f"{name}.activations.{m}.act.beta", (ch,), "normal", 0.3))
+    s.append(("activation_post.act.alpha", (ch,), "normal", 0.3))
+    s.append(("activation_post.act.beta", (ch,), "normal", 0.3))
+    _wn_conv(s, "conv_post", 1, ch, 7, 0.3 / math.sqrt(ch * 7))   # keeps tanh out of saturation on synthetic weights
+    return s
+
+
+def bigvgan_state_dict(cfg, seed: int = 0, round_to=None) -> Dict[str, torch.Tensor]:
+    return materialize(bigvgan_specs(cfg), seed, round_to)

@@ -255,6 +255,12 @@ int cv_sizeof_sample_params(void);
  * ------------------------------------------------------------------------------------------ */
 int cv_anti_alias_act(const void* x, void* y, int32_t dtype, int32_t B, int32_t C, int32_t T, const float* up_filter,
                       const float* down_filter, const float* alpha_log, const float* beta_log, void* stream);
+/* The same activation on channels-last tensors x [B][T][ldx] -> y [B][T][ldy] (first C channels), input / output element
+ * types chosen independently (fp32 residual stream in, 16-bit or fp32 conv operand out): the form the AMP blocks of
+ * BigVGAN.forward (BigVGAN/bigvgan.py:128-137,384-438) use between the channels-last conv GEMMs of this library. */
+int cv_anti_alias_act_cl(const void* x, int32_t ldx, int32_t in_dtype, void* y, int32_t ldy, int32_t out_dtype, int32_t B,
+                         int32_t T, int32_t C, const float* up_filter, const float* down_filter, const float* alpha_log,
+                         const float* beta_log, void* stream);
 
 #ifdef __cplusplus
 }

@@ -58,3 +58,47 @@ def anti_alias_activation(x: torch.Tensor, alpha_log: torch.Tensor, beta_log: to
     """Activation1d.forward (act.py:26-31): x [B,C,T] -> [B,C,T]."""
     f = kaiser_sinc_filter1d(0.25, 0.3, 12)
     return downsample2(snakebeta_log(upsample2(x, f), alpha_log, beta_log), f)
+
+
+# ------------------------------------------------------------------ full generator (BigVGAN/bigvgan.py:257-438)
+def _wn(sd, name):
+    from cosyvoice_amd.weights import fold_weight_norm
+    return fold_weight_norm(sd, name)
+
+
+def amp_block1(sd, name: str, x: torch.Tensor, k: int, dils) -> torch.Tensor:
+    """AMPBlock1.forward (bigvgan.py:128-137): per dilation  x = conv2(act2(conv1(act1(x)))) + x."""
+    for j, d in enumerate(dils):
+        a1, a2 = 2 * j, 2 * j + 1
+        xt = anti_alias_activation(x, sd[f"{name}.activations.{a1}.act.alpha"], sd[f"{name}.activations.{a1}.act.beta"])
+        xt = F.conv1d(xt, _wn(sd, f"{name}.convs1.{j}"), sd[f"{name}.convs1.{j}.bias"], dilation=d, padding=(k * d - d) // 2)
+        xt = anti_alias_activation(xt, sd[f"{name}.activations.{a2}.act.alpha"], sd[f"{name}.activations.{a2}.act.beta"])
+        xt = F.conv1d(xt, _wn(sd, f"{name}.convs2.{j}"), sd[f"{name}.convs2.{j}.bias"], padding=(k - 1) // 2)
+        x = xt + x
+    return x
+
+
+def bigvgan_forward(sd, cfg, token: torch.Tensor, token_len: torch.Tensor, embedding: torch.Tensor):
+    """BigVGAN.forward (bigvgan.py:384-438) with encoder1 = encoder2 = None.  token (B,N) int, token_len (B,),
+    embedding (B, D_spk) -> (wav (B, N * prod(upsample_rates)), mel_feat_out (B, N, mel_bin))."""
+    B, N = token.shape
+    spk = embedding.unsqueeze(-1).float()
+    mask = (torch.arange(N)[None, :] < token_len[:, None]).float().unsqueeze(-1)          # ~make_pad_mask
+    x = F.embedding(torch.clamp(token, min=0).long(), sd["input_embedding.weight"]) * mask
+    x = F.linear(x, sd["encoder_proj.weight"], sd["encoder_proj.bias"]).transpose(1, 2)
+    x = F.conv1d(x, _wn(sd, "conv_pre"), sd["conv_pre.bias"], padding=3)
+    x = x + F.conv1d(spk, sd["cond_layer.weight"], sd["cond_layer.bias"])
+    mel = F.linear(x.transpose(1, 2), sd["mel_proj.weight"], sd["mel_proj.bias"])
+    nk = len(cfg.resblock_kernel_sizes)
+    for i, (u, k) in enumerate(zip(cfg.upsample_rates, cfg.upsample_kernel_sizes)):
+        x = F.conv_transpose1d(x, _wn(sd, f"ups.{i}.0"), sd[f"ups.{i}.0.bias"], stride=u, padding=(k - u) // 2)
+        if cfg.cond_in_each_up_layer:
+            x = x + F.conv1d(spk, sd[f"conds.{i}.weight"], sd[f"conds.{i}.bias"])
+        xs = None
+        for j, (k2, dils) in enumerate(zip(cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes)):
+            y = amp_block1(sd, f"resblocks.{i * nk + j}", x, k2, dils)
+            xs = y if xs is None else xs + y
+        x = xs / nk
+    x = anti_alias_activation(x, sd["activation_post.act.alpha"], sd["activation_post.act.beta"])
+    x = F.conv1d(x, _wn(sd, "conv_post"), sd["conv_post.bias"], padding=3)
+    return torch.tanh(x).squeeze(1), mel

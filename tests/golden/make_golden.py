@@ -358,6 +358,38 @@ def golden_bigvgan_act():
          up_filter=m.upsample.filter.reshape(-1), down_filter=m.downsample.lowpass.filter.reshape(-1))
 
 
+def golden_bigvgan_model():
+    """The reference's BigVGAN generator itself (BigVGAN/bigvgan.py), encoder1 = encoder2 = None, torch activation path.
+    Its module imports the CUDA-extension loader at import time (cuda/activation1d.py:10 shells out to nvcc): that one
+    module is replaced by a name-only stub — use_cuda_kernel=False never touches it."""
+    from cosyvoice_amd.config import BigVGANConfig
+    from cosyvoice_amd.weights import bigvgan_state_dict
+    class _NameOnly:
+        pass
+    _stub("cosyvoice.BigVGAN.alias_free_activation.cuda")
+    _stub("cosyvoice.BigVGAN.alias_free_activation.cuda.activation1d", Activation1d=_NameOnly)
+    from cosyvoice.BigVGAN.bigvgan import BigVGAN
+    cfg = BigVGANConfig.tiny()
+    sd = bigvgan_state_dict(cfg, seed=5)
+    m = BigVGAN(vocab_size=cfg.vocab_size, input_size=cfg.input_size, output_size=cfg.output_size, mel_bin=cfg.mel_bin,
+                upsample_rates=list(cfg.upsample_rates), upsample_kernel_sizes=list(cfg.upsample_kernel_sizes),
+                upsample_initial_channel=cfg.upsample_initial_channel, resblock_kernel_sizes=list(cfg.resblock_kernel_sizes),
+                resblock_dilation_sizes=[list(d) for d in cfg.resblock_dilation_sizes],
+                speaker_embedding_dim=cfg.speaker_embedding_dim, use_cuda_kernel=False)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    missing = [k for k in missing if not k.endswith("filter")]   # the kaiser-sinc filters are buffers rebuilt at construction
+    assert not missing and not unexpected, (missing, unexpected)
+    m.eval()
+    g = torch.Generator().manual_seed(77)
+    B, N = 2, 21
+    token = torch.randint(0, cfg.vocab_size, (B, N), generator=g)
+    token_len = torch.tensor([N, N - 6])
+    emb = torch.randn(B, cfg.speaker_embedding_dim, generator=g)
+    with torch.inference_mode():
+        wav, (mel, _) = m(dict(speech_token=token, speech_token_len=token_len, embedding=emb), torch.device("cpu"))
+    save("bigvgan_tiny", token=token.to(torch.int32), token_len=token_len.to(torch.int32), embedding=emb, wav=wav, mel=mel, seed=np.array(5))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -371,6 +403,7 @@ def main():
         golden_llm()
     if "bigvgan" in which:
         golden_bigvgan_act()
+        golden_bigvgan_model()
 
 
 if __name__ == "__main__":

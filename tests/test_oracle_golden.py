@@ -115,3 +115,17 @@ def test_bigvgan_anti_alias_activation(golden_dir):
     assert (y - g["y"]).abs().max().item() < 1e-5
     assert (ob.kaiser_sinc_filter1d(0.25, 0.3, 12).reshape(-1) - g["up_filter"]).abs().max().item() < 1e-7
     assert (kaiser_sinc_filter12() - g["down_filter"]).abs().max().item() < 1e-7  # the product's own filter table
+
+
+def test_bigvgan_generator_vs_reference(golden_dir):
+    """oracle.bigvgan.bigvgan_forward against the reference's own BigVGAN.forward (golden minted by make_golden.py)."""
+    from cosyvoice_amd.config import BigVGANConfig
+    from cosyvoice_amd.weights import bigvgan_state_dict
+    from oracle import bigvgan as ob
+    g = _load(golden_dir, "bigvgan_tiny")
+    cfg = BigVGANConfig.tiny()
+    sd = bigvgan_state_dict(cfg, seed=int(g["seed"]))
+    wav, mel = ob.bigvgan_forward(sd, cfg, g["token"], g["token_len"], g["embedding"])
+    assert wav.shape == g["wav"].shape and mel.shape == g["mel"].shape
+    assert (wav - g["wav"]).abs().max().item() < 1e-5
+    assert (mel - g["mel"]).abs().max().item() < 1e-5
