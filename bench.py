@@ -96,8 +96,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flow-dtype", default="fp16", choices=["fp16", "bf16"])
-    ap.add_argument("--llm-cu-slots", type=int, default=12,
-                    help="CU slots per XCD (of 32) owned by the decode loop while it overlaps flow+HiFT; 0 = no partition")
+    ap.add_argument("--llm-cu-slots", type=int, default=8,
+                    help="CU slots per XCD (of 32) owned by the decode loops while they overlap flow+HiFT; 0 = no partition")
+    ap.add_argument("--llm-loops", type=int, default=2,
+                    help="concurrent decode loops (one utterance batch each, own KV caches) on the decode CUs")
     args = ap.parse_args()
 
     torch.set_num_threads(min(16, torch.get_num_threads()))  # CPU share per GPU on the box; keeps 8 ranks from oversubscribing
@@ -159,7 +161,7 @@ def main():
         """n pipeline passes ("steps"): LLM of pass i+1 overlaps flow + HiFT of pass i (two streams); every waveform is
         copied to the host inside the region."""
         last = None
-        for wav in model.tts_batches([make_batch() for _ in range(n)], to_host=True, llm_cu_slots=args.llm_cu_slots):
+        for wav in model.tts_batches([make_batch() for _ in range(n)], to_host=True, llm_cu_slots=args.llm_cu_slots, llm_loops=args.llm_loops):
             last = wav
         return last
 
@@ -217,7 +219,7 @@ def main():
             "config": {"workload": "C4 full LLM->flow->HiFT pipeline, 8 utterances x 10 s per GPU, 10 s prompt "
                                    "(prefill 282, N_g 250, flow T 1000 x 10 CFG Euler steps, HiFT 500 frames)",
                        "utterances_per_gpu": B, "rtf": round(elapsed / audio_s, 6), "parallelism": f"utterance-parallel x{world}",
-                       "llm_cu_slots_per_xcd": args.llm_cu_slots, "batch1": b1},
+                       "llm_cu_slots_per_xcd": args.llm_cu_slots, "llm_decode_loops": args.llm_loops, "batch1": b1},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

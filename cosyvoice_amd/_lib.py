@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcosyvoice_amd.so")
 
 CV_F32, CV_BF16, CV_F16 = 0, 1, 2
+CV_F32X3 = 3  # cv_gemm only: fp32 tensors, bf16x3 products
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_MISH, ACT_LEAKY, ACT_ELU, ACT_SNAKE, ACT_TANH, ACT_SWIGLU = range(9)
 OUT_ROWMAJOR, OUT_QKV = 0, 1
 

@@ -86,9 +86,10 @@ class BigVGAN:
     parallel AMP blocks and the final tanh all live in GEMM epilogues); the anti-aliased SnakeBeta is ``cv_anti_alias_act_cl``."""
 
     def __init__(self, cfg: Optional[BigVGANConfig] = None, dtype: torch.dtype = torch.float32, device: str = "cuda",
-                 encoder1=None, encoder2=None):
+                 encoder1=None, encoder2=None, f32_products: str = "bf16x3"):
         if not torch.cuda.is_available():
             raise RuntimeError("cosyvoice_amd needs an MI355X (no CPU fallback)")
+        self.f32_products = f32_products  # fp32 operands: "exact" f32 MFMA or bf16x3 split products (ops.f32_products)
         self.cfg = cfg or BigVGANConfig.full()
         self.dtype, self.device = dtype, torch.device(device)
         self.encoder1, self.encoder2 = encoder1, encoder2
@@ -189,6 +190,10 @@ class BigVGAN:
     # ------------------------------------------------------------------ BigVGAN.forward (bigvgan.py:384-438)
     @torch.no_grad()
     def forward(self, batch: dict, device=None):
+        with ops.f32_products(self.f32_products):
+            return self._forward(batch)
+
+    def _forward(self, batch: dict):
         assert self._loaded
         cfg, dt, dev = self.cfg, self.dtype, self.device
         token = batch["speech_token"].to(dev)

@@ -182,8 +182,14 @@ __device__ __forceinline__ void gemm_epilogue(const cv_gemm_params& p, f32x4_t (
 }
 
 // WM x WN waves per workgroup (NT_ = 64*WM*WN threads); each wave owns (BM/WM) x (BN/WN) of the tile.
-template <int DT, int BM, int BN, int WM = 2, int WN = 2>
+// X3 (fp32 tensors only): every product is computed as three bf16 MFMAs on hi/lo splits, a = a_hi + a_lo with
+// a_hi = bf16(a), a_lo = bf16(a - a_hi):  a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  (relative error ~2^-16, fp32 accumulate).
+// The split happens when a tile is written to LDS: the 128-byte row that held 32 floats holds 32 hi (chunks 0-3) + 32 lo
+// (chunks 4-7) bf16 values, i.e. exactly the two fragment reads of the 16-bit path, and 3 MFMA 16x16x32 replace the
+// 8 exact-f32 16x16x4 per K tile (the f32 MFMA peak is 1/16 of bf16: the HiFT / BigVGAN convs were MFMA-bound on it).
+template <int DT, int BM, int BN, int WM = 2, int WN = 2, bool X3 = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const cv_gemm_params p) {
+  static_assert(!X3 || DT == CV_F32, "the bf16x3 split is a mode of the fp32 path");
   constexpr int NTHR = 64 * WM * WN;
   constexpr int ES = ElemSize<DT>::value;
   constexpr int CH = 16 / ES;    // elements per 16-byte chunk
@@ -229,14 +235,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const cv_gemm_params
   uint4 ra[A_CH], rb[B_CH];
   uint32_t amask = 0, bmask = 0;        // validity bits of the prefetched chunks; applied when written to LDS
   const int k_last = p.K - CH;          // last valid chunk start
-  int a_m_ok[A_CH], a_rowbase[A_CH], a_tap[A_CH], a_ci[A_CH], a_lds[A_CH];
+  int a_m_ok[A_CH], a_rowbase[A_CH], a_tap[A_CH], a_ci[A_CH], a_lds[A_CH], a_lds2[A_CH];
   const char* a_ptr[A_CH];              // non-conv: fixed row, advances by 128 B per tile
 #pragma unroll
   for (int i = 0; i < A_CH; ++i) {
     const int c = i * NTHR + tid;
     const int row = c >> 3, kc = c & 7;  // 8 consecutive lanes = one 128-byte line of a row
     const int m = m0 + row;
-    a_lds[i] = lds_chunk_off(row, kc);
+    a_lds[i] = X3 ? lds_chunk_off(row, kc >> 1) + ((kc & 1) << 3) : lds_chunk_off(row, kc);   // X3: hi half-chunk
+    a_lds2[i] = lds_chunk_off(row, 4 + (kc >> 1)) + ((kc & 1) << 3);                            //     lo half-chunk
     a_m_ok[i] = m < p.M;
     a_rowbase[i] = m * p.a_row_stride + p.tap_base;
     const int k = kc * CH;
@@ -247,14 +254,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const cv_gemm_params
     a_ptr[i] = Ab + ((int64_t)arc * p.lda + k) * ES;
     if (!conv) a_m_ok[i] = a_m_ok[i] && (arow >= 0) && (arow < p.a_rows);
   }
-  int b_ok[B_CH], b_lds[B_CH], b_k[B_CH];
+  int b_ok[B_CH], b_lds[B_CH], b_lds2[B_CH], b_k[B_CH];
   const char* b_ptr[B_CH];
 #pragma unroll
   for (int i = 0; i < B_CH; ++i) {
     const int c = i * NTHR + tid;
     const int row = c >> 3, kc = c & 7;
     const int n = n0 + row;
-    b_lds[i] = BM * 128 + lds_chunk_off(row, kc);
+    b_lds[i] = BM * 128 + (X3 ? lds_chunk_off(row, kc >> 1) + ((kc & 1) << 3) : lds_chunk_off(row, kc));
+    b_lds2[i] = BM * 128 + lds_chunk_off(row, 4 + (kc >> 1)) + ((kc & 1) << 3);
     b_ok[i] = n < p.N;
     b_k[i] = kc * CH;
     b_ptr[i] = Wb + ((int64_t)min(n, p.N - 1) * p.ldw + kc * CH) * ES;
@@ -297,16 +305,42 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const cv_gemm_params
       bmask |= ((b_ok[i] && k < p.K) ? 1u : 0u) << i;
     }
   };
+  // X3: 4 floats -> 4 bf16 hi (8 bytes) + 4 bf16 lo (8 bytes)
+  auto split4 = [](const uint4& r, uint32_t mk, uint2& hi, uint2& lo) {
+    const float f[4] = {bitcast<float>(r.x & mk), bitcast<float>(r.y & mk), bitcast<float>(r.z & mk), bitcast<float>(r.w & mk)};
+    uint16_t h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      h[j] = Elem16<CV_BF16>::from_f32(f[j]);
+      l[j] = Elem16<CV_BF16>::from_f32(f[j] - Elem16<CV_BF16>::to_f32(h[j]));
+    }
+    hi = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+    lo = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+  };
   auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       const uint32_t mk = ((amask >> i) & 1u) ? 0xFFFFFFFFu : 0u;
-      *(uint4*)(smem + a_lds[i]) = make_uint4(ra[i].x & mk, ra[i].y & mk, ra[i].z & mk, ra[i].w & mk);
+      if constexpr (X3) {
+        uint2 hi, lo;
+        split4(ra[i], mk, hi, lo);
+        *(uint2*)(smem + a_lds[i]) = hi;
+        *(uint2*)(smem + a_lds2[i]) = lo;
+      } else {
+        *(uint4*)(smem + a_lds[i]) = make_uint4(ra[i].x & mk, ra[i].y & mk, ra[i].z & mk, ra[i].w & mk);
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
       const uint32_t mk = ((bmask >> i) & 1u) ? 0xFFFFFFFFu : 0u;
-      *(uint4*)(smem + b_lds[i]) = make_uint4(rb[i].x & mk, rb[i].y & mk, rb[i].z & mk, rb[i].w & mk);
+      if constexpr (X3) {
+        uint2 hi, lo;
+        split4(rb[i], mk, hi, lo);
+        *(uint2*)(smem + b_lds[i]) = hi;
+        *(uint2*)(smem + b_lds2[i]) = lo;
+      } else {
+        *(uint4*)(smem + b_lds[i]) = make_uint4(rb[i].x & mk, rb[i].y & mk, rb[i].z & mk, rb[i].w & mk);
+      }
     }
   };
 
@@ -324,6 +358,28 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const cv_gemm_params
   const char* sb = smem + BM * 128;
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) load_tile(kt + 1);
+    if constexpr (X3) {
+      uint4 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        ah[i] = *(const uint4*)(sa + ((wave_m * MT + i) << 11) + frag_off[0]);
+        al[i] = *(const uint4*)(sa + ((wave_m * MT + i) << 11) + frag_off[1]);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        bh[j] = *(const uint4*)(sb + ((wave_n * NT + j) << 11) + frag_off[0]);
+        bl[j] = *(const uint4*)(sb + ((wave_n * NT + j) << 11) + frag_off[1]);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          // small cross terms first, the dominant hi*hi last
+          acc[i][j] = mfma_block<CV_BF16>(bl[j], ah[i], acc[i][j]);
+          acc[i][j] = mfma_block<CV_BF16>(bh[j], al[i], acc[i][j]);
+          acc[i][j] = mfma_block<CV_BF16>(bh[j], ah[i], acc[i][j]);
+        }
+    } else
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       uint4 fa[MT], fb[NT];
@@ -346,12 +402,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const cv_gemm_params
   gemm_epilogue<DT, MT, NT>(p, acc, m0, n0, wave_m, wave_n, lane, z, z0, z1);
 }
 
-template <int DT, int BM, int BN, int WM = 2, int WN = 2>
+template <int DT, int BM, int BN, int WM = 2, int WN = 2, bool X3 = false>
 int launch(const cv_gemm_params& p, hipStream_t st) {
   const int mt = (p.M + BM - 1) / BM, nt = (p.N + BN - 1) / BN;
   dim3 grid(mt * nt, 1, p.batch);
   const size_t lds = (BM + BN) * 128;
-  hipLaunchKernelGGL((gemm_kernel<DT, BM, BN, WM, WN>), grid, dim3(64 * WM * WN), lds, st, p);
+  hipLaunchKernelGGL((gemm_kernel<DT, BM, BN, WM, WN, X3>), grid, dim3(64 * WM * WN), lds, st, p);
   CV_CHECK_LAUNCH();
   return CV_OK;
 }
@@ -511,6 +567,13 @@ int launch_ring(const cv_gemm_params& p, hipStream_t st) {
 // CV_GEMM_TILE=0|1|2|3 (128x128 | 128x64 | 64x64 | 128x128 LDS-DMA ring) overrides the heuristic: tuning aid only
 static int g_tile_override = -2;
 
+// fp32 tensors, bf16x3 products: the two register-staged tiles only
+int dispatch_x3(const cv_gemm_params& p, hipStream_t st) {
+  const long long t12864 = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * p.batch;
+  if (p.act == CV_ACT_SWIGLU || (p.K > 512 && t12864 >= 768)) return launch<CV_F32, 128, 64, 2, 2, true>(p, st);
+  return launch<CV_F32, 64, 64, 2, 2, true>(p, st);
+}
+
 template <int DT>
 int dispatch(const cv_gemm_params& p, hipStream_t st) {
   if (g_tile_override == -2) {
@@ -541,6 +604,8 @@ int dispatch(const cv_gemm_params& p, hipStream_t st) {
 extern "C" int cv_gemm(const cv_gemm_params* pp, void* stream) {
   if (!pp) return CV_ERR_ARG;
   cv_gemm_params p = *pp;
+  const bool x3 = p.dtype == CV_F32X3;   // fp32 tensors, bf16x3 products: everything below sees an fp32 GEMM
+  if (x3) p.dtype = CV_F32;
   const int es = p.dtype == CV_F32 ? 4 : 2;
   const int ch = 16 / es;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0) return CV_ERR_ARG;
@@ -570,6 +635,7 @@ extern "C" int cv_gemm(const cv_gemm_params* pp, void* stream) {
     if (p.out_act && ((p.ldoa & 3) || ((uintptr_t)p.out_act & 15) || (p.oa_bs0 & 3) || (p.oa_bs1 & 3))) return CV_ERR_ARG;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (x3) return dispatch_x3(p, st);
   switch (p.dtype) {
     case CV_F32: return dispatch<CV_F32>(p, st);
     case CV_BF16: return dispatch<CV_BF16>(p, st);

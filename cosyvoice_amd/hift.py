@@ -56,9 +56,14 @@ class _ConvT:
 
 
 class HiFTGenerator:
-    def __init__(self, cfg: Optional[HiftConfig] = None, dtype: torch.dtype = torch.float32, device: str = "cuda"):
+    def __init__(self, cfg: Optional[HiftConfig] = None, dtype: torch.dtype = torch.float32, device: str = "cuda",
+                 f32_products: str = "bf16x3"):
         self.cfg = cfg or HiftConfig.v2()
         self.dtype = dtype
+        # fp32 operands (the reference never halves HiFT): "exact" = f32 MFMA; "bf16x3" = three bf16 MFMAs on hi/lo splits per
+        # product (~2^-16 relative, ~3x faster) for the decoder convs.  The F0 predictor always runs exact: its output feeds a
+        # phase accumulation over 240 000 samples.
+        self.f32_products = f32_products
         self.device = torch.device(device)
         self.num_kernels = len(self.cfg.resblock_kernel_sizes)
         self.num_upsamples = len(self.cfg.upsample_rates)
@@ -212,6 +217,10 @@ class HiFTGenerator:
         return self._decode_cl(ws, B, T, s2)
 
     def _decode_cl(self, ws, B, T, s2):
+        with ops.f32_products(self.f32_products):
+            return self._decode_cl_impl(ws, B, T, s2)
+
+    def _decode_cl_impl(self, ws, B, T, s2):
         cfg = self.cfg
         ops.stft16(s2, ws["stft"])
         self._conv(self.conv_pre, ws["mel_cl"], act=ops.ACT_LEAKY, act_slope=cfg.lrelu_slope, out_act=ws["a_pre"])

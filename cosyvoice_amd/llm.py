@@ -13,6 +13,7 @@ Design (MI355X-first, not the reference's 4-graphs-per-layer path, llm/qwen2_5.p
   * weights: 16-bit, pre-packed at load into MFMA B-fragment order for the decode path (1 KiB per wave-load).
 Batching: B <= 16 sequences per step share every weight read (the reference is batch-1).
 """
+import copy
 import math
 import os
 from typing import Dict, Generator, List, Optional
@@ -99,6 +100,17 @@ class Qwen2LM:
         self._alloc_state()
         self._loaded = True
         return self
+
+    def new_context(self) -> "Qwen2LM":
+        """A second decode context over the SAME weights: own device state, KV caches, workspaces and captured graphs, so
+        two utterance batches can be decoded concurrently (two host threads, two streams).  The decode loop is a chain of
+        short latency-bound kernels: two interleaved chains raise the stage's throughput 1.5-1.6x on the same CUs
+        (tools/llm_dual_probe.py), which model.tts_batches uses."""
+        assert self._loaded
+        ctx = copy.copy(self)          # shares every weight tensor (they are never written after load_state_dict)
+        ctx._graphs, ctx._prefill_ws = {}, {}
+        ctx._alloc_state()
+        return ctx
 
     def _alloc_state(self):
         cfg, dt, dev = self.cfg, self.dtype, self.device

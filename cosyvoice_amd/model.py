@@ -49,7 +49,8 @@ class CosyVoice2Model:
         # high-priority side stream: the decode loop is a chain of short dependent kernels that must not queue behind the
         # flow GEMMs of the previous batch when both streams are busy (tts_batches)
         self.llm_context = torch.cuda.stream(torch.cuda.Stream(self.device, priority=-1))
-        self.llm_cu_slots = 12  # tts_batches: CU slots per XCD (of 32) owned by the decode loop; 0 = no partition
+        self.llm_cu_slots = 8   # tts_batches: CU slots per XCD (of 32) owned by the decode loops; 0 = no partition
+        self.llm_loops = 2      # tts_batches: concurrent decode loops (each its own batch / KV caches) on those CUs
         self.lock = threading.Lock()
         self.tts_speech_token_dict = {}
         self.llm_end_dict = {}
@@ -168,30 +169,48 @@ class CosyVoice2Model:
         wav, _ = self.hift.inference(speech_feat=mel.contiguous(), cache_source=torch.zeros(1, 1, 0))
         return wav.cpu() if to_host else wav
 
-    def cu_partition(self, llm_cu_slots: int):
-        """(llm_stream, flow_stream): CU-masked streams giving the decode loop ``llm_cu_slots`` of the 32 CUs of every XCD
-        and flow + HiFT the rest (cached).  With both stages free to use all 256 CUs the decode step's short dependent
-        kernels queue behind — and share CUs with — the flow GEMMs and run 1.6x slower while the two overlap (measured:
-        226 -> 368 ms per batch, tools/cumask_probe2.py); on disjoint CU sets neither disturbs the other."""
+    def cu_partition(self, llm_cu_slots: int, n_llm: int = 1):
+        """(llm_streams, flow_stream): CU-masked streams giving the decode loop(s) ``llm_cu_slots`` of the 32 CUs of every XCD
+        (one stream per concurrent decode loop, all on the same CUs) and flow + HiFT the rest (cached).  With both stages
+        free to use all 256 CUs the decode step's short dependent kernels queue behind — and share CUs with — the flow
+        GEMMs and run 1.6x slower while the two overlap (226 -> 368 ms per batch, tools/cumask_probe2.py); on disjoint CU
+        sets neither disturbs the other."""
         from . import ops
-        if getattr(self, "_cu_partition_key", None) != llm_cu_slots:
+        key = (llm_cu_slots, n_llm)
+        if getattr(self, "_cu_partition_key", None) != key:
             k = llm_cu_slots
-            self._cu_partition = (ops.masked_stream(lambda s, x: s < k), ops.masked_stream(lambda s, x: s >= k))
-            self._cu_partition_key = k
+            self._cu_partition = ([ops.masked_stream(lambda s, x: s < k) for _ in range(n_llm)],
+                                  ops.masked_stream(lambda s, x: s >= k),
+                                  ops.masked_stream(lambda s, x: s >= k))   # a decode loop borrowing the idle flow CUs
+            self._cu_partition_key = key
         return self._cu_partition
 
-    def tts_batches(self, batches, to_host: bool = True, llm_cu_slots: Optional[int] = None):
-        """Generator over a list of utterance batches (each a dict of tts_batch's arguments), software-pipelined the way
-        the reference overlaps its LLM thread with flow/HiFT (cli/model.py:62,119,189): the LLM decode of batch i+1
-        (latency-bound) runs while flow + HiFT of batch i (throughput-bound GEMMs) execute.  A batch may carry ``on_start``
-        (callable, e.g. the RCCL conditioning broadcast).
+    def llm_contexts(self, n: int):
+        """``n`` decode contexts over the one set of LLM weights (Qwen2LM.new_context)."""
+        ctxs = getattr(self, "_llm_contexts", None)
+        if ctxs is None or ctxs[0] is not self.llm:
+            ctxs = [self.llm]
+        while len(ctxs) < n:
+            ctxs.append(self.llm.new_context())
+        self._llm_contexts = ctxs
+        return ctxs[:n]
 
-        ``llm_cu_slots`` (default ``self.llm_cu_slots``) > 0 partitions the GPU: the decode loop runs on that many CUs
+    def tts_batches(self, batches, to_host: bool = True, llm_cu_slots: Optional[int] = None, llm_loops: Optional[int] = None):
+        """Generator over a list of utterance batches (each a dict of tts_batch's arguments), software-pipelined the way
+        the reference overlaps its LLM thread with flow/HiFT (cli/model.py:62,119,189): the LLM decode of later batches
+        (latency-bound) runs while flow + HiFT of batch i (throughput-bound GEMMs) execute.  A batch may carry ``on_start``
+        (callable, e.g. the RCCL conditioning broadcast; called from the calling thread, in batch order).
+
+        ``llm_cu_slots`` (default ``self.llm_cu_slots``) > 0 partitions the GPU: the decode loops run on that many CUs
         of every XCD and flow + HiFT on the others, each from its own host thread, every captured graph replayed launch by
-        launch (``ops.Graph.launch`` on a masked stream).  0 keeps both stages on all CUs (two plain streams)."""
+        launch (``ops.Graph.launch`` on a masked stream).  ``llm_loops`` (default ``self.llm_loops``) decode loops run
+        concurrently on the decode CUs, each on its own batch with its own KV caches: a decode step is a chain of 124 short
+        latency-bound kernels, and two interleaved chains deliver 1.5x the tokens per second of one.
+        ``llm_cu_slots=0`` keeps both stages on all CUs (two plain streams, one decode loop)."""
         k = self.llm_cu_slots if llm_cu_slots is None else llm_cu_slots
+        n = self.llm_loops if llm_loops is None else llm_loops
         if k:
-            yield from self._tts_batches_partitioned(batches, to_host, k)
+            yield from self._tts_batches_partitioned(batches, to_host, k, max(1, n))
         else:
             yield from self._tts_batches_shared(batches, to_host)
 
@@ -203,16 +222,33 @@ class CosyVoice2Model:
         wav, _ = self.hift.inference(speech_feat=mel.contiguous(), cache_source=torch.zeros(1, 1, 0))
         return wav
 
-    def _tts_batches_partitioned(self, batches, to_host, k):
+    def _tts_batches_partitioned(self, batches, to_host, k, n_llm):
+        import queue
+        from collections import deque
         from concurrent.futures import ThreadPoolExecutor
-        llm_part, flow_part = self.cu_partition(k)
-        llm_full = self.llm_context.stream  # all CUs: used while the other stage has nothing to run (pipeline fill / drain)
-        flow_full = torch.cuda.Stream(self.device)
+        llm_parts, flow_part, borrow_part = self.cu_partition(k, n_llm)
+        flow_full = torch.cuda.Stream(self.device)   # all CUs: the last batch's flow + HiFT run after every decode loop ended
         caller = torch.cuda.current_stream()
+        ctxs = queue.Queue()
+        for c, st in zip(self.llm_contexts(n_llm), llm_parts):
+            ctxs.put((c, st))
 
-        def flow_job(b, toks, ready, stream):
+        def llm_job(b, ready, borrow):
+            ctx, own = ctxs.get()
+            try:
+                # first batch of the run: the flow CUs are idle, decode there (more CUs, nothing to disturb)
+                stream = borrow_part if borrow else own
+                with torch.no_grad(), torch.cuda.stream(stream):
+                    stream.wait_event(ready)   # inputs the caller produced / the conditioning broadcast
+                    return ctx.generate_batch(b["texts"], b["prompt_texts"], b["llm_prompt_speech_tokens"],
+                                              forced=b.get("forced"), steps_per_poll=64)
+            finally:
+                ctxs.put((ctx, own))
+
+        def flow_job(b, llm_fut, ready, stream):
+            toks = llm_fut.result()
             with torch.no_grad(), torch.cuda.stream(stream):
-                stream.wait_event(ready)  # conditioning of this batch is in place
+                stream.wait_event(ready)
                 stream.wait_stream(flow_part if stream is flow_full else flow_full)  # workspaces of the previous batch
                 wav = self._flow_hift(b, toks)
                 if to_host:
@@ -228,26 +264,23 @@ class CosyVoice2Model:
             return wav
 
         it = iter(batches)
-        b = next(it, None)
-        pending = None
-        with ThreadPoolExecutor(max_workers=1) as pool:
-            while b is not None:
-                stream = llm_part if pending is not None else llm_full
-                with torch.no_grad(), torch.cuda.stream(stream):
-                    stream.wait_stream(caller)  # inputs the caller produced on its own stream
+        nxt = next(it, None)
+        inflight = deque()
+        first = True
+        with ThreadPoolExecutor(max_workers=n_llm) as llm_pool, ThreadPoolExecutor(max_workers=1) as flow_pool:
+            while nxt is not None or inflight:
+                # keep n_llm decode loops busy plus one batch queued behind them
+                while nxt is not None and len(inflight) < n_llm + 2:
+                    b, nxt = nxt, next(it, None)
                     if b.get("on_start") is not None:
-                        b["on_start"]()  # e.g. the conditioning broadcast: issued on the LLM stream, never behind flow work
+                        b["on_start"]()   # e.g. the conditioning broadcast: same order on every rank, never from worker threads
                     ready = torch.cuda.Event()
-                    ready.record(stream)
-                    toks = self.llm.generate_batch(b["texts"], b["prompt_texts"], b["llm_prompt_speech_tokens"],
-                                                   forced=b.get("forced"), steps_per_poll=64)
-                nxt = next(it, None)
-                fut = pool.submit(flow_job, b, toks, ready, flow_part if nxt is not None else flow_full)
-                if pending is not None:
-                    yield collect(pending)
-                pending, b = fut, nxt
-            if pending is not None:
-                yield collect(pending)
+                    ready.record(caller)
+                    lf = llm_pool.submit(llm_job, b, ready, first)
+                    ff = flow_pool.submit(flow_job, b, lf, ready, flow_part if nxt is not None else flow_full)
+                    inflight.append(ff)
+                    first = False
+                yield collect(inflight.popleft())
 
     @torch.no_grad()
     def _tts_batches_shared(self, batches, to_host):

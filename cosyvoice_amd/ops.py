@@ -1,6 +1,7 @@
 """Thin tensor-level wrappers over the C ABI (device pointers out of torch tensors; torch is plumbing only)."""
 import ctypes as C
 import sys
+import threading
 
 import torch
 
@@ -15,6 +16,26 @@ def _req_cuda(*ts):
             raise RuntimeError("cosyvoice_amd ops need device tensors (no CPU path)")
 
 
+_tls = threading.local()
+
+
+class f32_products:
+    """``with ops.f32_products("bf16x3"):`` — fp32 GEMMs / convs issued by this thread inside the block compute their
+    products as three bf16 MFMAs on hi/lo splits (cv_dtype CV_F32X3: ~2^-16 relative, fp32 accumulate, ~3x the exact-f32
+    MFMA rate) instead of the exact-f32 MFMA.  "exact" restores the default."""
+
+    def __init__(self, mode: str):
+        assert mode in ("exact", "bf16x3")
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "f32_mode", "exact")
+        _tls.f32_mode = self.mode
+
+    def __exit__(self, *exc):
+        _tls.f32_mode = self.prev
+
+
 def gemm(A, W, M, N, K, *, dtype=None, batch=1, batch_inner=0, a_bs=(0, 0), lda=None, a_rows=0, cin=0,
          a_row_stride=1, tap_base=0, tap_step=0, w_bs=(0, 0), ldw=None, bias=None, res=None, res_bs=(0, 0), ldres=0,
          res2=None, ldres2=0, out_scale=1.0, act=ACT_NONE, act_param=None, act_slope=0.0, out_f32=None, o32_bs=(0, 0),
@@ -22,6 +43,8 @@ def gemm(A, W, M, N, K, *, dtype=None, batch=1, batch_inner=0, a_bs=(0, 0), lda=
     _req_cuda(A, W, bias, res, res2, out_f32, out_act)
     p = L.GemmParams()
     p.dtype = L.TORCH_DT[A.dtype] if dtype is None else dtype
+    if dtype is None and A.dtype == torch.float32 and getattr(_tls, "f32_mode", "exact") == "bf16x3":
+        p.dtype = L.CV_F32X3
     p.M, p.N, p.K, p.batch, p.batch_inner = M, N, K, batch, batch_inner
     p.A, p.a_bs0, p.a_bs1, p.lda, p.a_rows = A.data_ptr(), a_bs[0], a_bs[1], (lda if lda is not None else A.stride(-2)), a_rows
     p.cin, p.a_row_stride, p.tap_base, p.tap_step = cin, a_row_stride, tap_base, tap_step

@@ -22,7 +22,9 @@ extern "C" {
 #endif
 
 typedef enum { CV_OK = 0, CV_ERR_ARG = -1, CV_ERR_LAUNCH = -2, CV_ERR_UNSUPPORTED = -3 } cv_status;
-typedef enum { CV_F32 = 0, CV_BF16 = 1, CV_F16 = 2 } cv_dtype;
+/* CV_F32X3 (cv_gemm only): fp32 tensors whose products are computed as three bf16 MFMAs on hi/lo splits (relative error
+ * ~2^-16, fp32 accumulate) instead of the exact-f32 MFMA, whose peak is 1/16 of the bf16 one. */
+typedef enum { CV_F32 = 0, CV_BF16 = 1, CV_F16 = 2, CV_F32X3 = 3 } cv_dtype;
 typedef enum {
   CV_ACT_NONE = 0, CV_ACT_GELU = 1, CV_ACT_SILU = 2, CV_ACT_MISH = 3, CV_ACT_LEAKY = 4,
   CV_ACT_ELU = 5, CV_ACT_SNAKE = 6, CV_ACT_TANH = 7, CV_ACT_SWIGLU = 8

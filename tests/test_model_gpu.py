@@ -77,7 +77,7 @@ def test_tts_batches_cu_partition_equals_shared_streams():
     """The CU-partitioned pipeline (decode loop and flow/HiFT on disjoint CU-masked streams, graphs replayed launch by
     launch from two host threads) produces bit-identical waveforms to the two-plain-streams pipeline."""
     m, lc, fc, hc = _model()
-    B, nb = 2, 3
+    B, nb = 2, 5
     shared = _inputs(lc, fc, seed=0)
     g = torch.Generator().manual_seed(11)
 
@@ -95,9 +95,9 @@ def test_tts_batches_cu_partition_equals_shared_streams():
 
     torch.manual_seed(0)
     ref = [w.clone() for w in m.tts_batches(batches(), llm_cu_slots=0)]
-    for k, to_host in ((12, True), (4, False)):
+    for k, loops, to_host in ((12, 1, True), (4, 2, False), (8, 3, True)):
         torch.manual_seed(0)
-        got = [w.cpu().clone() for w in m.tts_batches(batches(), to_host=to_host, llm_cu_slots=k)]
+        got = [w.cpu().clone() for w in m.tts_batches(batches(), to_host=to_host, llm_cu_slots=k, llm_loops=loops)]
         assert len(got) == nb
         for a, b in zip(ref, got):
             assert a.shape == b.shape and torch.isfinite(b).all()

@@ -34,7 +34,7 @@ def timed(fn, stream=None):
 print(f"graph replays, unmasked: LLM {timed(run_llm):.1f} ms, flow+HiFT {timed(run_fh):.1f} ms", flush=True)
 full = ops.masked_stream(lambda s, x: True)
 print(f"direct launches, all CUs: LLM {timed(run_llm, full):.1f} ms, flow+HiFT {timed(run_fh, full):.1f} ms", flush=True)
-for k in (4, 6, 8, 12, 16):
+for k in (10, 12, 14):
     sl = ops.masked_stream(lambda s, x: s < k)
     sf = ops.masked_stream(lambda s, x: s >= k)
     tl, tf = timed(run_llm, sl), timed(run_fh, sf)

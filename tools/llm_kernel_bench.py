@@ -16,7 +16,7 @@ llm.load_state_dict(llm_state_dict(lc))
 texts, forced, ptext, pspeech, pfeat, emb = B.make_inputs(lc, fc, 100)
 dev = 'cuda'; Bn = 8
 texts_d = [t.to(dev) for t in texts]; pt, ps = ptext.to(dev), pspeech.to(dev)
-llm.generate_batch(texts_d, [pt]*Bn, [ps]*Bn, forced=forced, max_steps=120)   # caches filled to ctx ~400, state valid
+llm.generate_batch(texts_d, [pt]*Bn, [ps]*Bn, forced=forced, max_steps=int(__import__('os').environ.get('LKB_STEPS', '120')))   # caches filled to ctx ~400, state valid
 torch.cuda.synchronize()
 cfg, st = llm.cfg, llm.st
 H, I = cfg.hidden_size, cfg.intermediate_size
@@ -35,6 +35,8 @@ def k_attn(li, lay):
 def k_o(li, lay): ops.skinny_gemm(st["ao"], lay["p_o"], Bn, H, cfg.q_dim, mode=1, out_f32=x2, ldo=H, max_wgs=CAP)
 def k_gu(li, lay):
     ops.skinny_gemm(st["xn"], lay["p_gu"], Bn, 2 * I, H, mode=2, out_act=st["h"], ldoa=I, norm=dict(x=x2, gamma=lay["g_post"], eps=cfg.rms_eps), max_wgs=CAP)
+def k_gu_nonorm(li, lay):   # ablation: the same weight stream and SwiGLU epilogue without the RMSNorm prologue
+    ops.skinny_gemm(st["xn"], lay["p_gu"], Bn, 2 * I, H, mode=2, out_act=st["h"], ldoa=I, max_wgs=CAP)
 def k_down(li, lay): ops.skinny_gemm(st["h"], lay["p_down"], Bn, H, I, ksplit=KS, out_f32=st["slabs"], ldo=H, slab_stride=16 * H, max_wgs=CAP)
 def k_final(li, lay): ops.rmsnorm_reduce(x, llm.g_final, cfg.rms_eps, st["xn"], Bn, slabs=st["slabs"], nslab=KS, slab_stride=16 * H, ld_slab=H)
 def k_head(li, lay): ops.skinny_gemm(st["xn"], llm.p_dec, Bn, cfg.out_vocab, H, bias=llm.dec_b, out_f32=st["logits"], ldo=llm.Vpad, max_wgs=CAP)
@@ -63,7 +65,9 @@ def bench(name, fn, per_rep, configs):
 full, part = torch.cuda.current_stream(), ops.masked_stream(lambda s_, x_: s_ < 13)
 configs = [(full, 0), (part, 0), (part, 104), (part, 208)]
 print("kernel      all CUs | 104 CUs, max_wgs = 0 / 104 / 208")
-for name, fn, per in (("qkv", k_qkv, 24), ("attn", k_attn, 24), ("o_proj", k_o, 24), ("gate_up", k_gu, 24), ("down", k_down, 24),
+only = __import__('os').environ.get('LKB_ONLY')
+for name, fn, per in (("qkv", k_qkv, 24), ("attn", k_attn, 24), ("o_proj", k_o, 24), ("gate_up", k_gu, 24), ("gu_nonorm", k_gu_nonorm, 24), ("down", k_down, 24),
                       ("final_norm", k_final, 24), ("head", k_head, 24)):
+    if only and name != only: continue
     bench(name, fn, per, configs if name not in ("attn", "final_norm") else configs[:2])
-bench("head+samp", k_sample, 24, configs[:1])   # per (head + memset + sampler) triple
+if not only: bench("head+samp", k_sample, 24, configs[:1])   # per (head + memset + sampler) triple
