@@ -158,8 +158,9 @@ def main():
                     flow_embeddings=em.expand(B, -1), forced=forced, on_start=bcast)
 
     def run_steps(n):
-        """n pipeline passes ("steps"): LLM of pass i+1 overlaps flow + HiFT of pass i (two streams); every waveform is
-        copied to the host inside the region."""
+        """n pipeline passes ("steps", one batch of 8 utterances each): the decode loops of later passes (two at a time, on
+        their CU share) overlap flow + HiFT of pass i (on the other CUs); every waveform is copied to the host inside the
+        region."""
         last = None
         for wav in model.tts_batches([make_batch() for _ in range(n)], to_host=True, llm_cu_slots=args.llm_cu_slots, llm_loops=args.llm_loops):
             last = wav
@@ -214,7 +215,7 @@ def main():
             "value": round(audio_s / elapsed, 3), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": f"llm bf16 / flow {args.flow_dtype} MFMA operands, fp32 accumulate; hift f32 MFMA",
+            "dtype": f"llm bf16 / flow {args.flow_dtype} MFMA operands, fp32 accumulate; hift fp32 tensors, bf16x3 split-product MFMA",
             "data": "synthetic (key-seeded random weights of the reference architecture, teacher-forced 250 tokens)",
             "config": {"workload": "C4 full LLM->flow->HiFT pipeline, 8 utterances x 10 s per GPU, 10 s prompt "
                                    "(prefill 282, N_g 250, flow T 1000 x 10 CFG Euler steps, HiFT 500 frames)",

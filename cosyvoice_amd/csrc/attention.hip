@@ -18,8 +18,10 @@ constexpr int VT_BYTES = 64 * VT_PITCH;
 constexpr int STAGE_BYTES = KT_BYTES + VT_BYTES;
 constexpr float NEG_BIG = -1e30f;
 
+// launch bound 3 workgroups per CU (168 VGPRs, no spills): the kernel is stall-bound, not issue-bound (3 600 cycles per
+// tile-wave against ~900 of issue), so a third resident wave per SIMD bought 97 -> 83 us; a fourth needs 128 VGPRs and spills.
 template <int DT>
-__global__ __launch_bounds__(256) void attn_kernel(const cv_attn_params p) {
+__global__ __launch_bounds__(256, 3) void attn_kernel(const cv_attn_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lq = lane & 15, lg = lane >> 4;
