@@ -103,3 +103,25 @@ def test_inference_vs_oracle_larger_and_batched(dt, linf, l1):
     mg = flow.inference_batch(tok, ptok, pfeat, emb).clone()  # replays
     torch.cuda.synchronize()
     assert (mg - mb).abs().max().item() < 1e-6
+
+
+def test_inference_without_prompt_and_minimal_length():
+    """Edge cases of flow.inference (flow.py:258-319): no prompt at all (N_p = 0: cond is all zeros, nothing is sliced off)
+    and the shortest inputs (one generated token = two mel frames, with and without a prompt)."""
+    from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
+    from oracle import flow as of
+    cfg = FlowConfig.tiny()
+    sd = flow_state_dict(cfg)
+    flow = CausalMaskedDiffWithXvec(cfg, dtype=torch.float16).load_state_dict(sd)
+    g = torch.Generator().manual_seed(11)
+    emb = torch.randn(1, cfg.spk_embed_dim, generator=g)
+    for n_p, n_g in ((0, 9), (0, 1), (3, 1)):
+        tok = torch.randint(0, cfg.vocab_size, (1, n_g), generator=g, dtype=torch.int32)
+        ptok = torch.randint(0, cfg.vocab_size, (1, n_p), generator=g, dtype=torch.int32)
+        pfeat = torch.clamp(torch.randn(1, 2 * n_p, 80, generator=g) * 2 - 6, -11.5, 2.0)
+        ref = of.inference(sd, cfg, tok, ptok, pfeat, emb)
+        mel, cache = flow.inference(token=tok, token_len=torch.tensor([n_g]), prompt_token=ptok, prompt_token_len=torch.tensor([n_p]),
+                                    prompt_feat=pfeat, prompt_feat_len=torch.tensor([2 * n_p]), embedding=emb, finalize=True)
+        assert cache is None and mel.shape == (1, 80, 2 * n_g) and mel.dtype == torch.float32
+        a, b = _report(f"mel[N_p={n_p},N_g={n_g}]", mel, ref)
+        assert a < 2e-2 and b < 5e-3

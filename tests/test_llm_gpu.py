@@ -272,3 +272,32 @@ def test_generation_first_tokens_match_oracle():
         print(f"seq {b}: oracle {len(ref)} tokens, hip {len(got[b])} tokens, exact prefix {first_diff}")
         assert n > 0 and ref[0] == got[b][0]
         assert 10 <= len(got[b]) <= 100  # min/max token-text ratios respected
+
+
+def test_inference_without_prompt_and_single_text_token():
+    """Edge cases of Qwen2LM.inference (llm.py:823-874): empty prompt text AND empty prompt speech (zero-shot without a
+    prompt: lm_input = [sos, text, task_id]) and a one-token text (min_len 2, max_len 20).  The generator yields python
+    ints within the token-text ratio bounds; the first token equals the oracle's."""
+    from cosyvoice_amd.llm import Qwen2LM
+    from oracle import llm as ol
+    cfg = LlmConfig.tiny()
+    sd = llm_state_dict(cfg, round_to=torch.bfloat16)
+    lm = Qwen2LM(cfg, dtype=torch.bfloat16, max_batch=4, ctx_max=256, max_out=256).load_state_dict(sd)
+    g = torch.Generator().manual_seed(5)
+    uni = torch.zeros(16, 101, 2)
+    uni[:, :, 0] = torch.rand(16, 101, generator=g) * 0.6
+    uni[:, :, 1] = torch.rand(16, 101, generator=g)
+    empty_i = torch.zeros(1, 0, dtype=torch.int32)
+    for n_text in (6, 1):
+        text = torch.randint(0, cfg.vocab_size, (1, n_text), generator=g, dtype=torch.int32)
+        got = lm.generate_batch([text], [empty_i], [empty_i], uniforms=uni)[0]
+        ref = list(ol.lm_inference(sd, cfg, text, empty_i, empty_i, uniforms=lambda t: tuple(uni[0, t].tolist())))
+        assert 2 * n_text <= len(got) <= 20 * n_text
+        assert all(isinstance(t, int) and 0 <= t < cfg.speech_token_size for t in got)
+        assert got[0] == ref[0]
+        # the reference-signature generator gives the same stream of ints
+        lm.seed = 0
+        toks = list(lm.inference(text=text.cuda(), text_len=torch.tensor([n_text], dtype=torch.int32), prompt_text=empty_i.cuda(),
+                                 prompt_text_len=torch.tensor([0], dtype=torch.int32), prompt_speech_token=empty_i.cuda(),
+                                 prompt_speech_token_len=torch.tensor([0], dtype=torch.int32), embedding=torch.zeros(0, 192)))
+        assert 2 * n_text <= len(toks) <= 20 * n_text and all(isinstance(t, int) for t in toks)
