@@ -123,7 +123,8 @@ EXPORTS = ["cv_version", "cv_arch", "cv_gemm", "cv_layernorm", "cv_attention",
            "cv_embedding", "cv_est_pack", "cv_cfm_update", "cv_graph_begin", "cv_graph_end", "cv_graph_launch",
            "cv_graph_destroy", "cv_graph_launch_direct", "cv_graph_num_launches", "cv_stream_create_cumask",
            "cv_stream_destroy", "cv_skinny_gemm", "cv_pack_skinny", "cv_rmsnorm_reduce", "cv_rope_append",
-           "cv_decode_attention", "cv_sample_ras", "cv_sizeof_skinny_params", "cv_sizeof_sample_params", "cv_anti_alias_act", "cv_anti_alias_act_cl"]
+           "cv_decode_attention", "cv_sample_ras", "cv_sizeof_skinny_params", "cv_sizeof_sample_params", "cv_anti_alias_act", "cv_anti_alias_act_cl",
+           "cv_stft_magnitude", "cv_log_clamp_channels_first"]
 
 TORCH_DT = {torch.float32: CV_F32, torch.bfloat16: CV_BF16, torch.float16: CV_F16}
 DT_TORCH = {v: k for k, v in TORCH_DT.items()}

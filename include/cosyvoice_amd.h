@@ -154,6 +154,16 @@ int cv_est_pack(const float* x, const float* mu, const float* spks, const float*
 int cv_cfm_update(float* x, const float* v, int32_t B, int32_t T, int32_t C, float dt, float cfg_rate, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Prompt-feature front half: mel_spectrogram (cosyvoice/dataset/processor_kaldidata.py:37-74; 24 kHz: n_fft = win 1920,
+ * hop 480, 80 mels, center=False with (n_fft-hop)/2 reflect padding).  The windowed DFT and the mel projection are cv_gemm
+ * calls (frames are a strided view of the padded signal: lda = hop); these are the two element-wise steps.
+ * ------------------------------------------------------------------------------------------ */
+/* spec [rows][ld_spec] = [re(nbins) | im(nbins) | pad] -> mag [rows][ld_mag] = sqrt(re^2 + im^2 + eps) (:66), columns >= nbins zeroed */
+int cv_stft_magnitude(const float* spec, int32_t ld_spec, float* mag, int32_t ld_mag, int32_t rows, int32_t nbins, float eps, void* stream);
+/* mel [B][T][ld] -> out [B][n_mels][T] = log(max(mel, clip)) (dynamic_range_compression_torch :27-28) */
+int cv_log_clamp_channels_first(const float* mel, int32_t ld, float* out, int32_t B, int32_t T, int32_t n_mels, float clip, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * hipGraph capture of a launch sequence issued through this ABI on `stream` (the reference's counterpart is
  * torch.cuda.CUDAGraph capture in llm/qwen2_5.py:97-124).  begin/end bracket the launches; launch replays them.
  * ------------------------------------------------------------------------------------------ */

@@ -390,11 +390,31 @@ def golden_bigvgan_model():
     save("bigvgan_tiny", token=token.to(torch.int32), token_len=token_len.to(torch.int32), embedding=emb, wav=wav, mel=mel, seed=np.array(5))
 
 
+def golden_frontend_mel():
+    """The reference's own mel_spectrogram (dataset/processor_kaldidata.py:37-74) at the CosyVoice2 configuration, with
+    librosa.filters.mel (absent, unpinned) replaced by the build's restatement of its default algorithm: pins everything
+    after the basis (reflect pad, hann STFT, magnitude, projection, log-compression)."""
+    from cosyvoice_amd.frontend import slaney_mel_basis
+    _stub("librosa")
+    _stub("librosa.filters", mel=lambda sr, n_fft, n_mels, fmin, fmax: slaney_mel_basis(sr, n_fft, n_mels, fmin, fmax))
+    sys.modules["torchaudio"].set_audio_backend = lambda *a, **k: None
+    from cosyvoice.dataset.processor_kaldidata import mel_spectrogram
+    g = torch.Generator().manual_seed(123)
+    t = torch.arange(2 * 24000 + 317) / 24000.0
+    y = 0.4 * torch.sin(2 * torch.pi * 220.0 * t) + 0.2 * torch.sin(2 * torch.pi * 3100.0 * t * (1 + 0.1 * t)) \
+        + 0.05 * torch.randn(t.shape, generator=g)
+    y = torch.stack([y, torch.flip(y, dims=[0]) * 0.5]).clamp(-1, 1)
+    with torch.inference_mode():
+        mel = mel_spectrogram(y, n_fft=1920, num_mels=80, sampling_rate=24000, hop_size=480, win_size=1920, fmin=0, fmax=8000,
+                              center=False)
+    save("frontend_mel", y=y, mel=mel)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     install_stubs()
-    which = sys.argv[1:] or ["hift", "flow", "llm", "bigvgan"]
+    which = sys.argv[1:] or ["hift", "flow", "llm", "bigvgan", "frontend"]
     if "hift" in which:
         golden_hift()
     if "flow" in which:
@@ -404,6 +424,8 @@ def main():
     if "bigvgan" in which:
         golden_bigvgan_act()
         golden_bigvgan_model()
+    if "frontend" in which:
+        golden_frontend_mel()
 
 
 if __name__ == "__main__":

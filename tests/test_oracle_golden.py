@@ -129,3 +129,27 @@ def test_bigvgan_generator_vs_reference(golden_dir):
     assert wav.shape == g["wav"].shape and mel.shape == g["mel"].shape
     assert (wav - g["wav"]).abs().max().item() < 1e-5
     assert (mel - g["mel"]).abs().max().item() < 1e-5
+
+
+def test_frontend_mel_vs_reference(golden_dir):
+    """oracle.frontend.mel_spectrogram against the reference's own function (librosa's mel basis replaced by the restated one
+    on both sides: that boundary is unpinned), plus sanity of the restated Slaney basis."""
+    from cosyvoice_amd.frontend import align_prompt_24k, slaney_mel_basis
+    from oracle import frontend as ofe
+    g = _load(golden_dir, "frontend_mel")
+    basis = torch.from_numpy(slaney_mel_basis(24000, 1920, 80, 0, 8000))
+    mel = ofe.mel_spectrogram(g["y"], basis)
+    assert mel.shape == g["mel"].shape
+    assert (mel - g["mel"]).abs().max().item() < 1e-4
+    assert basis.shape == (80, 961) and (basis >= 0).all()
+    peak = basis.argmax(dim=1)
+    assert (peak[1:] > peak[:-1]).all()                        # centre frequencies increase
+    assert basis[:, 961 * 8000 // 12000 + 2:].abs().max() == 0  # nothing above fmax
+    # Slaney normalisation: every triangle has unit area in Hz (bin width 12.5 Hz), up to sampling of the triangle
+    area = basis.sum(dim=1) * 12.5
+    assert (area - 1.0).abs().max().item() < 0.08
+    # cli/frontend.py:148-152
+    f, fl, t, tl = align_prompt_24k(torch.zeros(1, 101, 80), torch.zeros(1, 60, dtype=torch.int32))
+    assert f.shape[1] == 100 and int(fl) == 100 and t.shape[1] == 50 and int(tl) == 50
+    f, fl, t, tl = align_prompt_24k(torch.zeros(1, 100, 80), torch.zeros(1, 37, dtype=torch.int32))
+    assert f.shape[1] == 74 and t.shape[1] == 37
