@@ -265,8 +265,11 @@ class Qwen2LM:
     def generate_batch(self, texts: List[torch.Tensor], prompt_texts: List[torch.Tensor], prompt_speech: List[torch.Tensor],
                        forced: Optional[List[List[int]]] = None, uniforms: Optional[torch.Tensor] = None,
                        max_token_text_ratio: float = 20, min_token_text_ratio: float = 2, steps_per_poll: int = 16,
-                       max_steps: Optional[int] = None) -> List[List[int]]:
-        """Run B sequences (equal prompt length) to completion; returns the emitted token lists."""
+                       max_steps: Optional[int] = None, prefill_stream=None) -> List[List[int]]:
+        """Run B sequences (equal prompt length) to completion; returns the emitted token lists.
+        ``prefill_stream``: run the prefill (throughput-bound GEMMs / attention over B*Lp rows) on that stream instead of the
+        current one — model.tts_batches hands it a stream on the flow stage's CUs, so the few-CU decode partition only ever
+        runs the latency-bound token loop."""
         assert self._loaded
         B = len(texts)
         assert 1 <= B <= self.max_batch
@@ -294,8 +297,16 @@ class Qwen2LM:
         use_uniforms = uniforms is not None
         if use_uniforms:
             st["uniforms"].copy_(uniforms.to(torch.float32))
-        self._assemble_inputs(ws, texts, prompt_texts, prompt_speech, B, Lp)
-        self._prefill(B, Lp, use_forced, use_uniforms)
+        if prefill_stream is not None:
+            cur = torch.cuda.current_stream()
+            prefill_stream.wait_stream(cur)            # the state resets above
+            with torch.cuda.stream(prefill_stream):
+                self._assemble_inputs(ws, texts, prompt_texts, prompt_speech, B, Lp)
+                self._prefill(B, Lp, use_forced, use_uniforms)
+            cur.wait_stream(prefill_stream)            # KV caches, first token and decode state are in place
+        else:
+            self._assemble_inputs(ws, texts, prompt_texts, prompt_speech, B, Lp)
+            self._prefill(B, Lp, use_forced, use_uniforms)
         limit = int(mx[:B].max()) if max_steps is None else max_steps
         done_steps = 1
         while done_steps < limit:

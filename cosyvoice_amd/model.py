@@ -181,7 +181,8 @@ class CosyVoice2Model:
             k = llm_cu_slots
             self._cu_partition = ([ops.masked_stream(lambda s, x: s < k) for _ in range(n_llm)],
                                   ops.masked_stream(lambda s, x: s >= k),
-                                  ops.masked_stream(lambda s, x: s >= k))   # a decode loop borrowing the idle flow CUs
+                                  ops.masked_stream(lambda s, x: s >= k),   # a decode loop borrowing the idle flow CUs
+                                  [ops.masked_stream(lambda s, x: s >= k) for _ in range(n_llm)])  # prefills, on the flow CUs
             self._cu_partition_key = key
         return self._cu_partition
 
@@ -226,24 +227,26 @@ class CosyVoice2Model:
         import queue
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
-        llm_parts, flow_part, borrow_part = self.cu_partition(k, n_llm)
+        llm_parts, flow_part, borrow_part, prefill_parts = self.cu_partition(k, n_llm)
         flow_full = torch.cuda.Stream(self.device)   # all CUs: the last batch's flow + HiFT run after every decode loop ended
         caller = torch.cuda.current_stream()
         ctxs = queue.Queue()
-        for c, st in zip(self.llm_contexts(n_llm), llm_parts):
-            ctxs.put((c, st))
+        for c, st, pf in zip(self.llm_contexts(n_llm), llm_parts, prefill_parts):
+            ctxs.put((c, st, pf))
 
         def llm_job(b, ready, borrow):
-            ctx, own = ctxs.get()
+            ctx, own, pf = ctxs.get()
             try:
                 # first batch of the run: the flow CUs are idle, decode there (more CUs, nothing to disturb)
                 stream = borrow_part if borrow else own
                 with torch.no_grad(), torch.cuda.stream(stream):
                     stream.wait_event(ready)   # inputs the caller produced / the conditioning broadcast
+                    # the prefill is throughput-bound GEMM work: it runs beside flow + HiFT on their (three times larger)
+                    # CU share, the decode partition only runs the token loop
                     return ctx.generate_batch(b["texts"], b["prompt_texts"], b["llm_prompt_speech_tokens"],
-                                              forced=b.get("forced"), steps_per_poll=64)
+                                              forced=b.get("forced"), steps_per_poll=64, prefill_stream=None if borrow else pf)
             finally:
-                ctxs.put((ctx, own))
+                ctxs.put((ctx, own, pf))
 
         def flow_job(b, llm_fut, ready, stream):
             toks = llm_fut.result()
