@@ -241,7 +241,11 @@ class BigVGAN:
                      out_f32=ws["mel"].view(B * N, -1), ldo32=cfg.mel_bin)
             mel = ws["mel"]
         else:
-            mel = torch.nn.functional.linear(mel_from_enc, self.mel_w.float(), self.mel_b)  # encoder2-width mel head (:405)
+            # encoder2-width mel head (:405): the same GEMM, on the encoder output
+            enc = mel_from_enc.to(dt).contiguous().view(B * N, -1)
+            mel = torch.empty(B, N, cfg.mel_bin, device=dev)
+            ops.gemm(enc, self.mel_w, B * N, cfg.mel_bin, self.mel_w.shape[1], lda=enc.stride(0), bias=self.mel_b,
+                     out_f32=mel.view(B * N, -1), ldo32=cfg.mel_bin)
         cur_a, t_in = ws["x0a"], N
         nk = self.num_kernels
         for i in range(self.num_upsamples):

@@ -78,17 +78,27 @@ def amp_block1(sd, name: str, x: torch.Tensor, k: int, dils) -> torch.Tensor:
     return x
 
 
-def bigvgan_forward(sd, cfg, token: torch.Tensor, token_len: torch.Tensor, embedding: torch.Tensor):
-    """BigVGAN.forward (bigvgan.py:384-438) with encoder1 = encoder2 = None.  token (B,N) int, token_len (B,),
-    embedding (B, D_spk) -> (wav (B, N * prod(upsample_rates)), mel_feat_out (B, N, mel_bin))."""
+def bigvgan_forward(sd, cfg, token: torch.Tensor, token_len: torch.Tensor, embedding: torch.Tensor, encoder1=None, encoder2=None):
+    """BigVGAN.forward (bigvgan.py:384-438).  token (B,N) int, token_len (B,), embedding (B, D_spk) ->
+    (wav (B, N' * prod(upsample_rates)), mel_feat_out (B, N', mel_bin)); encoder1 / encoder2: the injected x2-upsampling
+    encoders ``(x, x_len) -> (y, mask)`` (:395-402), None = tokens go straight to encoder_proj (N' = N)."""
     B, N = token.shape
     spk = embedding.unsqueeze(-1).float()
     mask = (torch.arange(N)[None, :] < token_len[:, None]).float().unsqueeze(-1)          # ~make_pad_mask
     x = F.embedding(torch.clamp(token, min=0).long(), sd["input_embedding.weight"]) * mask
+    mel = None
+    if encoder1 is not None:
+        x, _ = encoder1(x, token_len)
+        token_len = token_len * 2
+    if encoder2 is not None:
+        x, _ = encoder2(x, token_len)
+        token_len = token_len * 2
+        mel = F.linear(x, sd["mel_proj.weight"], sd["mel_proj.bias"])
     x = F.linear(x, sd["encoder_proj.weight"], sd["encoder_proj.bias"]).transpose(1, 2)
     x = F.conv1d(x, _wn(sd, "conv_pre"), sd["conv_pre.bias"], padding=3)
     x = x + F.conv1d(spk, sd["cond_layer.weight"], sd["cond_layer.bias"])
-    mel = F.linear(x.transpose(1, 2), sd["mel_proj.weight"], sd["mel_proj.bias"])
+    if mel is None:
+        mel = F.linear(x.transpose(1, 2), sd["mel_proj.weight"], sd["mel_proj.bias"])
     nk = len(cfg.resblock_kernel_sizes)
     for i, (u, k) in enumerate(zip(cfg.upsample_rates, cfg.upsample_kernel_sizes)):
         x = F.conv_transpose1d(x, _wn(sd, f"ups.{i}.0"), sd[f"ups.{i}.0.bias"], stride=u, padding=(k - u) // 2)

@@ -118,3 +118,33 @@ def test_generator_full_config_vs_oracle():
     assert wav.shape == (B, N * 1024) and torch.isfinite(wav).all()
     assert (wav.cpu() - ref_wav).abs().max().item() < 2e-3
     assert (mel.cpu() - ref_mel).abs().max().item() < 1e-3 * max(1.0, ref_mel.abs().max().item())
+
+
+def test_generator_with_injected_encoders():
+    """encoder1 / encoder2 are injected modules in the reference (bigvgan.py:273-285,395-402): each doubles the frame rate;
+    with encoder2 present mel_proj reads the encoder output.  Stand-in encoders (nearest x2 + a fixed mixing) on both sides."""
+    from cosyvoice_amd.bigvgan import BigVGAN
+    from cosyvoice_amd.config import BigVGANConfig
+    from cosyvoice_amd.weights import bigvgan_state_dict
+    from oracle import bigvgan as ob
+    cfg = BigVGANConfig.tiny()
+    sd = bigvgan_state_dict(cfg, seed=4)
+    D = cfg.input_size
+    # with encoder2 the reference sizes encoder_proj / mel_proj by encoder2.output_size(): same width here, new mel_proj
+    g = torch.Generator().manual_seed(8)
+    sd["mel_proj.weight"] = torch.randn(cfg.mel_bin, D, generator=g) / D ** 0.5
+    mix = torch.randn(D, D, generator=g) / D ** 0.5
+
+    def enc(x, n):   # (B,T,D) -> (B,2T,D)
+        return torch.tanh(x.repeat_interleave(2, dim=1) @ mix.to(x.device)), None
+
+    B, N = 2, 9
+    token = torch.randint(0, cfg.vocab_size, (B, N), generator=g)
+    token_len = torch.tensor([9, 5])
+    emb = torch.randn(B, cfg.speaker_embedding_dim, generator=g)
+    ref_wav, ref_mel = ob.bigvgan_forward(sd, cfg, token, token_len, emb, encoder1=enc, encoder2=enc)
+    m = BigVGAN(cfg, dtype=torch.float32, encoder1=enc, encoder2=enc).load_state_dict(sd)
+    wav, (mel, _) = m(dict(speech_token=token, speech_token_len=token_len, embedding=emb), "cuda")
+    assert wav.shape == ref_wav.shape == (B, 4 * N * cfg.total_upsample) and mel.shape == ref_mel.shape == (B, 4 * N, cfg.mel_bin)
+    assert (wav.cpu() - ref_wav).abs().max().item() < 3e-4
+    assert (mel.cpu() - ref_mel).abs().max().item() < 3e-4
