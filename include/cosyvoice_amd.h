@@ -254,6 +254,9 @@ typedef struct cv_sample_params {
   float* x; int32_t ldx;      /* next-step input embedding [B][ldx] */
 } cv_sample_params;
 int cv_sample_ras(const cv_sample_params* p, void* stream);
+int cv_sizeof_gemm_params(void);
+int cv_sizeof_norm_params(void);
+int cv_sizeof_attn_params(void);
 int cv_sizeof_skinny_params(void);
 int cv_sizeof_sample_params(void);
 
