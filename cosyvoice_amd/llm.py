@@ -202,9 +202,12 @@ class Qwen2LM:
         g.launch()
 
     # ------------------------------------------------------------------ prefill
-    def _prefill(self, B, Lp, use_forced, use_uniforms):
+    def _prefill(self, B, Lp, use_forced, use_uniforms, lens=None):
         """Input embeddings already in ws['x'] (B*Lp, H) fp32.  Writes the KV caches for positions [0,Lp), leaves the
-        last position's hidden state in st['x'] and runs head + sampling (llm.py:861-866, first loop iteration)."""
+        last position's hidden state in st['x'] and runs head + sampling (llm.py:861-866, first loop iteration).
+        ``lens`` (list of B ints <= Lp): ragged batch, sequence b occupies rows [0, lens[b]) of its Lp-row slot (the rest are
+        zero embeddings): attention is limited to its own keys, its decode state starts at lens[b]; the cache entries the
+        padded rows write beyond lens[b] are never read (decode attends to ctx_len keys) and get overwritten as b grows."""
         cfg, dt, dev, st = self.cfg, self.dtype, self.device, self.st
         H, I = cfg.hidden_size, cfg.intermediate_size
         qkv_dim = cfg.q_dim + 2 * cfg.kv_dim
@@ -213,6 +216,9 @@ class Qwen2LM:
         x = ws["x"]
         st["pos"].zero_()
         scale = 1.0 / math.sqrt(cfg.head_dim)
+        klen = None
+        if lens is not None and any(l != Lp for l in lens):
+            klen = torch.tensor(list(lens), dtype=torch.int32, device=dev)
         for li, lay in enumerate(self.layers):
             ops.layernorm(x, lay["g_in"], None, cfg.rms_eps, rms=True, out_act=ws["xn"])
             ops.linear(ws["xn"], lay["wqkv"], bias=lay["bqkv"], out_f32=ws["qkv"])
@@ -220,14 +226,20 @@ class Qwen2LM:
                             self.vtcache[li], self.ctx_max)
             ops.attention(ws["q"], self.kcache[li], self.vtcache[li], ws["ao"], B=B, H=cfg.num_heads, Hkv=cfg.num_kv_heads, Tq=Lp,
                           Tk=Lp, scale=scale, q_bs=Lp * cfg.q_dim, ldq=cfg.q_dim, k_bs=cfg.num_kv_heads * self.ctx_max * 64,
-                          k_hs=self.ctx_max * 64, ldk=64, vt_ld=self.ctx_max, o_bs=Lp * cfg.q_dim, ldo=cfg.q_dim, causal=True)
+                          k_hs=self.ctx_max * 64, ldk=64, vt_ld=self.ctx_max, o_bs=Lp * cfg.q_dim, ldo=cfg.q_dim, causal=True,
+                          klen=klen)
             ops.linear(ws["ao"], lay["wo"], res=x, out_f32=x)
             ops.layernorm(x, lay["g_post"], None, cfg.rms_eps, rms=True, out_act=ws["xn"])
             ops.linear(ws["xn"], lay["wgu"], act=ops.ACT_SWIGLU, out_act=ws["h"])
             ops.linear(ws["h"], lay["wdown"], res=x, out_f32=x)
         # last position of every sequence -> decode state
-        st["x"][:B].copy_(x.view(B, Lp, H)[:, Lp - 1])
-        st["pos"][:B].fill_(Lp - 1)  # the sampler's +1 then makes pos = Lp = cache length
+        if klen is None:
+            st["x"][:B].copy_(x.view(B, Lp, H)[:, Lp - 1])
+            st["pos"][:B].fill_(Lp - 1)  # the sampler's +1 then makes pos = Lp = cache length
+        else:
+            last = (klen - 1).long()
+            st["x"][:B].copy_(x.view(B, Lp, H)[torch.arange(B, device=dev), last])
+            st["pos"][:B].copy_(klen - 1)
         ops.rmsnorm_reduce(st["x"], self.g_final, cfg.rms_eps, st["xn"], B)
         self._head_and_sample(B, use_forced, use_uniforms)
 
@@ -252,11 +264,13 @@ class Qwen2LM:
             t = torch.cat([prompt_texts[b].reshape(-1).to(dev), texts[b].reshape(-1).to(dev)]).to(torch.int32)
             ps = prompt_speech[b].reshape(-1).to(dev, torch.int32)
             lt, lps = t.numel(), ps.numel()
-            assert 1 + lt + 1 + lps == Lp, "batched prefill needs equal prompt lengths"
+            n = 1 + lt + 1 + lps
+            assert n <= Lp
             idx[2, b, 0] = self.sos_eos
             idx[0, b, 1:1 + lt] = t
             idx[2, b, 1 + lt] = self.task_id
-            idx[1, b, 2 + lt:] = ps
+            idx[1, b, 2 + lt:n] = ps
+            idx[0, b, n:] = -1   # ragged batch: rows beyond this sequence are zero embeddings
         for k, table in enumerate((self.embed_tokens, self.speech_embedding, self.llm_embedding)):
             ops.embedding(table, ws["idx"][k], ws["x"])
 
@@ -266,7 +280,7 @@ class Qwen2LM:
                        forced: Optional[List[List[int]]] = None, uniforms: Optional[torch.Tensor] = None,
                        max_token_text_ratio: float = 20, min_token_text_ratio: float = 2, steps_per_poll: int = 16,
                        max_steps: Optional[int] = None, prefill_stream=None) -> List[List[int]]:
-        """Run B sequences (equal prompt length) to completion; returns the emitted token lists.
+        """Run B sequences (any mix of text / prompt lengths) to completion; returns the emitted token lists.
         ``prefill_stream``: run the prefill (throughput-bound GEMMs / attention over B*Lp rows) on that stream instead of the
         current one — model.tts_batches hands it a stream on the flow stage's CUs, so the few-CU decode partition only ever
         runs the latency-bound token loop."""
@@ -274,7 +288,8 @@ class Qwen2LM:
         B = len(texts)
         assert 1 <= B <= self.max_batch
         st = self.st
-        Lp = 1 + prompt_texts[0].numel() + texts[0].numel() + 1 + prompt_speech[0].numel()
+        lens = [1 + prompt_texts[b].numel() + texts[b].numel() + 1 + prompt_speech[b].numel() for b in range(B)]
+        Lp = max(lens)   # ragged batches are left-aligned in Lp-row slots
         ws = self._prefill_workspace(B, Lp)
         for k in ("step", "n_emitted", "finished"):
             st[k].zero_()
@@ -285,7 +300,7 @@ class Qwen2LM:
             tl = texts[b].numel()  # text_len - prompt_text_len (llm.py:855-856)
             mn[b] = int(tl * min_token_text_ratio)
             mx[b] = int(tl * max_token_text_ratio)
-            assert Lp + int(mx[b]) <= self.ctx_max, "ctx_max too small"
+            assert lens[b] + int(mx[b]) <= self.ctx_max and Lp <= self.ctx_max, "ctx_max too small"
         st["min_len"].copy_(mn)
         st["max_len"].copy_(mx)
         use_forced = forced is not None
@@ -302,11 +317,11 @@ class Qwen2LM:
             prefill_stream.wait_stream(cur)            # the state resets above
             with torch.cuda.stream(prefill_stream):
                 self._assemble_inputs(ws, texts, prompt_texts, prompt_speech, B, Lp)
-                self._prefill(B, Lp, use_forced, use_uniforms)
+                self._prefill(B, Lp, use_forced, use_uniforms, lens)
             cur.wait_stream(prefill_stream)            # KV caches, first token and decode state are in place
         else:
             self._assemble_inputs(ws, texts, prompt_texts, prompt_speech, B, Lp)
-            self._prefill(B, Lp, use_forced, use_uniforms)
+            self._prefill(B, Lp, use_forced, use_uniforms, lens)
         limit = int(mx[:B].max()) if max_steps is None else max_steps
         done_steps = 1
         while done_steps < limit:

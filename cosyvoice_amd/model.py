@@ -160,13 +160,13 @@ class CosyVoice2Model:
     def tts_batch(self, texts: List[torch.Tensor], prompt_texts: List[torch.Tensor], llm_prompt_speech_tokens: List[torch.Tensor],
                   flow_prompt_speech_tokens: torch.Tensor, prompt_speech_feats: torch.Tensor, flow_embeddings: torch.Tensor,
                   forced: Optional[List[List[int]]] = None, to_host: bool = True):
-        """B equal-shape utterances through LLM -> flow -> HiFT.  Returns wav (B,S)."""
+        """B utterances (texts / prompts of any lengths) through LLM -> flow -> HiFT.  Returns wav (B,S) when all sequences
+        generated the same number of tokens (teacher-forced), else a list of B waveforms."""
         toks = self.llm.generate_batch(texts, prompt_texts, llm_prompt_speech_tokens, forced=forced)
-        n = min(len(t) for t in toks)
-        assert all(len(t) == n for t in toks), "tts_batch needs equal generated lengths (use forced tokens or per-utterance tts)"
-        tok = torch.tensor(toks, dtype=torch.int32, device=self.device)
-        mel = self.flow.inference_batch(tok, flow_prompt_speech_tokens, prompt_speech_feats, flow_embeddings)
-        wav, _ = self.hift.inference(speech_feat=mel.contiguous(), cache_source=torch.zeros(1, 1, 0))
+        wav = self._flow_hift(dict(flow_prompt_speech_tokens=flow_prompt_speech_tokens, prompt_speech_feats=prompt_speech_feats,
+                                   flow_embeddings=flow_embeddings), toks)
+        if isinstance(wav, list):   # sequences of different generated lengths
+            return [w.cpu() for w in wav] if to_host else wav
         return wav.cpu() if to_host else wav
 
     def cu_partition(self, llm_cu_slots: int, n_llm: int = 1):
@@ -216,12 +216,24 @@ class CosyVoice2Model:
             yield from self._tts_batches_shared(batches, to_host)
 
     def _flow_hift(self, b, toks):
+        """Flow + HiFT of one batch.  Equal generated lengths (teacher-forced runs, the benchmark): one batched pass ->
+        wav (B, S).  Free-running sampling ends every sequence at its own step: flow + HiFT then run per utterance (the
+        batched flow path assumes one common length) -> list of B waveforms (S_b,)."""
         n = len(toks[0])
-        assert all(len(t) == n for t in toks), "tts_batches needs equal generated lengths per batch"
-        tok = torch.tensor(toks, dtype=torch.int32, device=self.device)
-        mel = self.flow.inference_batch(tok, b["flow_prompt_speech_tokens"], b["prompt_speech_feats"], b["flow_embeddings"])
-        wav, _ = self.hift.inference(speech_feat=mel.contiguous(), cache_source=torch.zeros(1, 1, 0))
-        return wav
+        zero = torch.zeros(1, 1, 0)
+        if all(len(t) == n for t in toks):
+            tok = torch.tensor(toks, dtype=torch.int32, device=self.device)
+            mel = self.flow.inference_batch(tok, b["flow_prompt_speech_tokens"], b["prompt_speech_feats"], b["flow_embeddings"])
+            wav, _ = self.hift.inference(speech_feat=mel.contiguous(), cache_source=zero)
+            return wav
+        outs = []
+        for i, t in enumerate(toks):
+            tok = torch.tensor([t], dtype=torch.int32, device=self.device)
+            mel = self.flow.inference_batch(tok, b["flow_prompt_speech_tokens"][i:i + 1], b["prompt_speech_feats"][i:i + 1],
+                                            b["flow_embeddings"][i:i + 1])
+            wav, _ = self.hift.inference(speech_feat=mel.contiguous(), cache_source=zero)
+            outs.append(wav[0].clone())
+        return outs
 
     def _tts_batches_partitioned(self, batches, to_host, k, n_llm):
         import queue
@@ -255,7 +267,7 @@ class CosyVoice2Model:
                 stream.wait_stream(flow_part if stream is flow_full else flow_full)  # workspaces of the previous batch
                 wav = self._flow_hift(b, toks)
                 if to_host:
-                    return wav.cpu(), None
+                    return ([w.cpu() for w in wav] if isinstance(wav, list) else wav.cpu()), None
                 done = torch.cuda.Event()
                 done.record(stream)
                 return wav, done
@@ -299,7 +311,10 @@ class CosyVoice2Model:
                     ready.record(llm_stream)
                     toks = self.llm.generate_batch(b["texts"], b["prompt_texts"], b["llm_prompt_speech_tokens"], forced=b.get("forced"))
             if pending is not None:
-                yield pending.cpu() if to_host else pending.clone()
+                if isinstance(pending, list):
+                    yield [w.cpu() for w in pending] if to_host else pending
+                else:
+                    yield pending.cpu() if to_host else pending.clone()
                 pending = None
             if toks is not None:
                 torch.cuda.current_stream().wait_event(ready)  # conditioning of this batch is in place

@@ -301,3 +301,28 @@ def test_inference_without_prompt_and_single_text_token():
                                  prompt_text_len=torch.tensor([0], dtype=torch.int32), prompt_speech_token=empty_i.cuda(),
                                  prompt_speech_token_len=torch.tensor([0], dtype=torch.int32), embedding=torch.zeros(0, 192)))
         assert 2 * n_text <= len(toks) <= 20 * n_text and all(isinstance(t, int) for t in toks)
+
+
+def test_ragged_batch_equals_single_sequences():
+    """generate_batch over sequences of different text / prompt lengths (left-aligned slots, per-sequence attention length
+    and decode position) emits exactly the tokens each sequence emits when run alone with the same uniforms."""
+    from cosyvoice_amd.llm import Qwen2LM
+    cfg = LlmConfig.tiny()
+    sd = llm_state_dict(cfg, round_to=torch.bfloat16)
+    lm = Qwen2LM(cfg, dtype=torch.bfloat16, max_batch=4, ctx_max=256, max_out=256).load_state_dict(sd)
+    g = torch.Generator().manual_seed(21)
+    shapes = [(5, 3, 7), (2, 0, 0), (9, 4, 12), (1, 1, 3)]          # (text, prompt text, prompt speech) lengths
+    texts = [torch.randint(0, cfg.vocab_size, (1, a), generator=g, dtype=torch.int32) for a, _, _ in shapes]
+    ptexts = [torch.randint(0, cfg.vocab_size, (1, b), generator=g, dtype=torch.int32) for _, b, _ in shapes]
+    pspeech = [torch.randint(0, cfg.speech_token_size, (1, c), generator=g, dtype=torch.int32) for _, _, c in shapes]
+    uni = torch.zeros(16, 101, 2)
+    uni[:, :, 0] = torch.rand(16, 101, generator=g) * 0.6
+    uni[:, :, 1] = torch.rand(16, 101, generator=g)
+    got = lm.generate_batch(texts, ptexts, pspeech, uniforms=uni)
+    assert len({len(t) for t in got}) > 1                                # sequences end at different steps
+    for b, (a, _, _) in enumerate(shapes):
+        assert 2 * a <= len(got[b]) <= 20 * a
+        u1 = uni.clone()
+        u1[0] = uni[b]
+        alone = lm.generate_batch([texts[b]], [ptexts[b]], [pspeech[b]], uniforms=u1)[0]
+        assert alone == got[b], (b, alone[:8], got[b][:8])

@@ -102,3 +102,23 @@ def test_tts_batches_cu_partition_equals_shared_streams():
         for a, b in zip(ref, got):
             assert a.shape == b.shape and torch.isfinite(b).all()
             assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_tts_batch_free_running_ragged_lengths():
+    """Without teacher forcing every utterance (different text lengths) stops at its own step: tts_batch returns one
+    waveform per utterance, 2 * hop * n_tokens samples each."""
+    m, lc, fc, hc = _model()
+    ins = [_inputs(lc, fc, seed=s, n_text=n) for s, n in ((1, 3), (2, 6), (3, 4))]
+    shared = ins[0]
+    B = len(ins)
+    torch.manual_seed(0)
+    wavs = m.tts_batch([i["text"] for i in ins], [shared["prompt_text"]] * B, [shared["llm_prompt_speech_token"]] * B,
+                       shared["flow_prompt_speech_token"].expand(B, -1), shared["prompt_speech_feat"].expand(B, -1, -1),
+                       shared["flow_embedding"].expand(B, -1))
+    wavs = wavs if isinstance(wavs, list) else list(wavs)
+    assert len(wavs) == B
+    for w, i in zip(wavs, ins):
+        n = w.numel() // (2 * hc.total_upsample)
+        assert w.numel() == n * 2 * hc.total_upsample and 2 * i["text"].shape[1] <= n <= 20 * i["text"].shape[1]
+        assert torch.isfinite(w).all() and w.abs().max() <= 0.99 + 1e-6
