@@ -274,13 +274,26 @@ class Qwen2LM:
         for k, table in enumerate((self.embed_tokens, self.speech_embedding, self.llm_embedding)):
             ops.embedding(table, ws["idx"][k], ws["x"])
 
+    def _assemble(self, ws, texts, prompt_texts, prompt_speech, B, Lp, lm_inputs):
+        if lm_inputs is None:
+            return self._assemble_inputs(ws, texts, prompt_texts, prompt_speech, B, Lp)
+        x = ws["x"].view(B, Lp, -1)
+        x.zero_()   # rows beyond a sequence's own length are zero embeddings
+        for b, e in enumerate(lm_inputs):
+            x[b, :e.shape[0]].copy_(e.to(self.device, torch.float32))
+
     # ------------------------------------------------------------------ public API
     @torch.no_grad()
     def generate_batch(self, texts: List[torch.Tensor], prompt_texts: List[torch.Tensor], prompt_speech: List[torch.Tensor],
                        forced: Optional[List[List[int]]] = None, uniforms: Optional[torch.Tensor] = None,
                        max_token_text_ratio: float = 20, min_token_text_ratio: float = 2, steps_per_poll: int = 16,
-                       max_steps: Optional[int] = None, prefill_stream=None) -> List[List[int]]:
+                       max_steps: Optional[int] = None, prefill_stream=None,
+                       lm_inputs: Optional[List[torch.Tensor]] = None) -> List[List[int]]:
         """Run B sequences (any mix of text / prompt lengths) to completion; returns the emitted token lists.
+        ``lm_inputs``: per sequence a ready-made prefill embedding sequence (L_b, hidden) fp32 instead of the
+        [sos, embed(prompt_text + text), task_id, speech_emb(prompt_speech)] assembly — the hook for the fork's other LM
+        front-ends, which differ from Qwen2LM only in how lm_input is built (e.g. Qwen2LM_Phoneme_Src2, llm.py:1687-1745:
+        [sos, spk, fused phoneme sequence, task_id, prompt speech]); ``texts`` still gives the min/max length ratios.
         ``prefill_stream``: run the prefill (throughput-bound GEMMs / attention over B*Lp rows) on that stream instead of the
         current one — model.tts_batches hands it a stream on the flow stage's CUs, so the few-CU decode partition only ever
         runs the latency-bound token loop."""
@@ -288,7 +301,11 @@ class Qwen2LM:
         B = len(texts)
         assert 1 <= B <= self.max_batch
         st = self.st
-        lens = [1 + prompt_texts[b].numel() + texts[b].numel() + 1 + prompt_speech[b].numel() for b in range(B)]
+        if lm_inputs is not None:
+            assert len(lm_inputs) == B and all(e.dim() == 2 and e.shape[1] == self.cfg.hidden_size for e in lm_inputs)
+            lens = [int(e.shape[0]) for e in lm_inputs]
+        else:
+            lens = [1 + prompt_texts[b].numel() + texts[b].numel() + 1 + prompt_speech[b].numel() for b in range(B)]
         Lp = max(lens)   # ragged batches are left-aligned in Lp-row slots
         ws = self._prefill_workspace(B, Lp)
         for k in ("step", "n_emitted", "finished"):
@@ -316,11 +333,11 @@ class Qwen2LM:
             cur = torch.cuda.current_stream()
             prefill_stream.wait_stream(cur)            # the state resets above
             with torch.cuda.stream(prefill_stream):
-                self._assemble_inputs(ws, texts, prompt_texts, prompt_speech, B, Lp)
+                self._assemble(ws, texts, prompt_texts, prompt_speech, B, Lp, lm_inputs)
                 self._prefill(B, Lp, use_forced, use_uniforms, lens)
             cur.wait_stream(prefill_stream)            # KV caches, first token and decode state are in place
         else:
-            self._assemble_inputs(ws, texts, prompt_texts, prompt_speech, B, Lp)
+            self._assemble(ws, texts, prompt_texts, prompt_speech, B, Lp, lm_inputs)
             self._prefill(B, Lp, use_forced, use_uniforms, lens)
         limit = int(mx[:B].max()) if max_steps is None else max_steps
         done_steps = 1

@@ -326,3 +326,29 @@ def test_ragged_batch_equals_single_sequences():
         u1[0] = uni[b]
         alone = lm.generate_batch([texts[b]], [ptexts[b]], [pspeech[b]], uniforms=u1)[0]
         assert alone == got[b], (b, alone[:8], got[b][:8])
+
+
+def test_generate_from_ready_made_prefill_embeddings():
+    """lm_inputs hook: feeding the embedding sequence the standard assembly would build (llm.py:837-852) gives the same tokens
+    as the id-based path, also in a ragged batch."""
+    import torch.nn.functional as F
+    from cosyvoice_amd.llm import Qwen2LM
+    cfg = LlmConfig.tiny()
+    sd = llm_state_dict(cfg, round_to=torch.bfloat16)
+    lm = Qwen2LM(cfg, dtype=torch.bfloat16, max_batch=4, ctx_max=256, max_out=256).load_state_dict(sd)
+    g = torch.Generator().manual_seed(33)
+    shapes = [(4, 2, 5), (7, 0, 0)]
+    texts = [torch.randint(0, cfg.vocab_size, (1, a), generator=g, dtype=torch.int32) for a, _, _ in shapes]
+    ptexts = [torch.randint(0, cfg.vocab_size, (1, b), generator=g, dtype=torch.int32) for _, b, _ in shapes]
+    pspeech = [torch.randint(0, cfg.speech_token_size, (1, c), generator=g, dtype=torch.int32) for _, _, c in shapes]
+    uni = torch.zeros(16, 101, 2)
+    uni[:, :, 0] = torch.rand(16, 101, generator=g) * 0.6
+    uni[:, :, 1] = torch.rand(16, 101, generator=g)
+    want = lm.generate_batch(texts, ptexts, pspeech, uniforms=uni)
+    embs = []
+    for t, pt, ps in zip(texts, ptexts, pspeech):
+        te = F.embedding(torch.cat([pt, t], 1).long()[0], sd["llm.model.model.embed_tokens.weight"].float())
+        pe = F.embedding(ps.long()[0], sd["speech_embedding.weight"].float())
+        embs.append(torch.cat([sd["llm_embedding.weight"][0:1].float(), te, sd["llm_embedding.weight"][1:2].float(), pe], 0))
+    got = lm.generate_batch(texts, ptexts, pspeech, uniforms=uni, lm_inputs=embs)
+    assert got == want
