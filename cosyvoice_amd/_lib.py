@@ -86,6 +86,7 @@ class SampleParams(C.Structure):
         ("logits", _vp), ("ldl", _i32), ("V", _i32), ("B", _i32),
         ("eos", _i32), ("top_k", _i32), ("top_p", _f32), ("win_size", _i32), ("tau_r", _f32),
         ("seed", C.c_uint64),
+        ("fallback_mode", _i32), ("top_p2", _f32), ("top_k2", _i32),
         ("uniforms", _vp), ("max_trials", _i32),
         ("min_len", _vp), ("max_len", _vp),
         ("forced", _vp), ("forced_ld", _i32),

@@ -188,3 +188,46 @@ class BigVGANConfig:
     def tiny() -> "BigVGANConfig":
         return BigVGANConfig(vocab_size=64, input_size=32, output_size=48, upsample_rates=(4, 2), upsample_kernel_sizes=(8, 4),
                              upsample_initial_channel=64, speaker_embedding_dim=16)
+
+
+@dataclass(frozen=True)
+class PhonemeFrontConfig:
+    # Qwen2LM_Phoneme_Src2 (/root/reference/cosyvoice/llm/llm.py:1450-1531) as configured by
+    # examples/tts_vc/cosyvoice2/conf/cosyvoice_pho_tts.yaml:29-73: 4-factor phoneme embedding -> ConformerEncoder
+    # (rel-pos, no cnn, no macaron) -> affine -> one DecoderLayer (self-attn + src-attn over the BPE text embeddings)
+    text_token_size: int = 140
+    text_token_dim: int = 400
+    text_tone_size: int = 16
+    text_tone_dim: int = 64
+    text_lang_size: int = 2
+    text_lang_dim: int = 16
+    text_prsd_size: int = 6
+    text_prsd_dim: int = 32
+    enc_dim: int = 1024
+    enc_heads: int = 16
+    enc_linear_units: int = 4096
+    enc_blocks: int = 6
+    src_heads: int = 16          # hard-coded in the reference (llm.py:1503-1505)
+    src_linear_units: int = 4096
+    spk_embed_dim: int = 192
+    use_frontend_prsd: bool = False
+    # sampling: cosyvoice.utils.common.non_random_ras_sampling (yaml :67-72)
+    top_p: float = 0.8
+    top_k: int = 10
+    win_size: int = 10
+    tau_r: float = 0.1
+    expand_scale: int = 2
+
+    @property
+    def input_size(self) -> int:
+        return self.text_token_dim + self.text_tone_dim + self.text_lang_dim + self.text_prsd_dim
+
+    @staticmethod
+    def full() -> "PhonemeFrontConfig":
+        return PhonemeFrontConfig()
+
+    @staticmethod
+    def tiny() -> "PhonemeFrontConfig":
+        return PhonemeFrontConfig(text_token_size=30, text_token_dim=24, text_tone_size=5, text_tone_dim=8, text_lang_size=2,
+                                  text_lang_dim=8, text_prsd_size=4, text_prsd_dim=8, enc_dim=128, enc_heads=2,
+                                  enc_linear_units=256, enc_blocks=2, spk_embed_dim=16)   # src_heads / src_linear_units are hard-coded in the reference

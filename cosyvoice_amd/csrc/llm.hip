@@ -874,6 +874,10 @@ __global__ __launch_bounds__(256) void sample_kernel(const cv_sample_params p) {
   // first version extracted the maxima one by one: top_k x (32-value scan + 12 dependent cross-lane steps + 2 barriers),
   // 39 us per token.)  A pool overflow (near-constant logits) falls back to that loop.
   const int top_k = min(p.top_k, 64);
+  // fallback_mode 1 (non_random_ras_sampling, utils/common.py:116-123): the repetition fallback is a second, wider nucleus
+  // (top_p2, top_k2) over the same sorted candidates, so the candidate pass runs to the larger of the two k
+  const int top_k2 = p.fallback_mode == 1 ? min(p.top_k2, 64) : 0;
+  const int kth = max(top_k, top_k2);
   s_scan[tid] = lmax;
   __syncthreads();
   {
@@ -886,7 +890,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const cv_sample_params p) {
       rank += (o.z > lmax || (o.z == lmax && i + 2 < tid)) ? 1 : 0;
       rank += (o.w > lmax || (o.w == lmax && i + 3 < tid)) ? 1 : 0;
     }
-    if (rank == top_k - 1) s_thr = lmax;
+    if (rank == kth - 1) s_thr = lmax;
   }
   __syncthreads();
   const float thr = s_thr;
@@ -900,8 +904,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const cv_sample_params p) {
   }
   __syncthreads();
   const int pool = s_cnt;
-  int ncand = 0;
-  float cum = 0.f;
+  int nsorted;   // candidates in s_candp / s_candi, descending probability, lower index first on ties
   if (pool <= SC_CAP) {
     if (tid < pool) {
       const BestKV mine{s_cv[tid], s_ci[tid]};
@@ -912,19 +915,13 @@ __global__ __launch_bounds__(256) void sample_kernel(const cv_sample_params p) {
       }
       if (rank < 64) { s_candp[rank] = mine.v; s_candi[rank] = mine.i; }
     }
+    nsorted = min(kth, pool);
     __syncthreads();
-    // sequential fp32 prefix in candidate order (the reference's accumulation order), on wave-uniform values
-    const int kmax = min(top_k, pool);
-    const float cp = s_candp[min(lane, max(kmax - 1, 0))];
-#pragma unroll
-    for (int i = 0; i < 64; ++i) {
-      if (i >= kmax || cum >= p.top_p) break;
-      cum += lane_bcast(cp, i);
-      ++ncand;
-    }
   } else {
     uint32_t taken = 0;
-    while (ncand < top_k && cum < p.top_p) {
+    int n = 0;
+    const int want = min(kth, V);
+    while (n < want) {
       BestKV best{-1.f, 0x7fffffff};
 #pragma unroll
       for (int j = 0; j < SV_PER; ++j)
@@ -939,11 +936,31 @@ __global__ __launch_bounds__(256) void sample_kernel(const cv_sample_params p) {
       best = better(better(s_best[0], s_best[1]), better(s_best[2], s_best[3]));
       __syncthreads();
       if ((best.i & 255) == tid) taken |= 1u << (best.i >> 8);
-      if (tid == 0) { s_candp[ncand] = best.v; s_candi[ncand] = best.i; }
-      cum += best.v;
+      if (tid == 0) { s_candp[n] = best.v; s_candi[n] = best.i; }
+      ++n;
+    }
+    nsorted = want;
+    __syncthreads();
+  }
+  // nucleus prefixes: sequential fp32 accumulation in candidate order (the reference's order), on wave-uniform values
+  const float cp = s_candp[min(lane, max(nsorted - 1, 0))];
+  int ncand = 0, ncand2 = 0;
+  float cum = 0.f, cum2 = 0.f;
+  {
+    const int kmax = min(top_k, nsorted);
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      if (i >= kmax || cum >= p.top_p) break;
+      cum += lane_bcast(cp, i);
       ++ncand;
     }
-    __syncthreads();
+    const int kmax2 = min(top_k2, nsorted);
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      if (i >= kmax2 || cum2 >= p.top_p2) break;
+      cum2 += lane_bcast(cp, i);
+      ++ncand2;
+    }
   }
 
   // ---- trials (llm.py:813-820): redraw while EOS is sampled before min_len
@@ -965,6 +982,8 @@ __global__ __launch_bounds__(256) void sample_kernel(const cv_sample_params p) {
       // nucleus draw: inverse CDF over the candidate probabilities (renormalised); candidates live one per lane
       const float cpl = s_candp[min(lane, max(ncand - 1, 0))];
       const int cil = s_candi[min(lane, max(ncand - 1, 0))];
+      const float cpl2 = s_candp[min(lane, max(ncand2 - 1, 0))];
+      const int cil2 = s_candi[min(lane, max(ncand2 - 1, 0))];
       const float target = u1 * cum;
       float c = 0.f;
       int pick = ncand - 1;
@@ -977,9 +996,23 @@ __global__ __launch_bounds__(256) void sample_kernel(const cv_sample_params p) {
       const int tok = __shfl(cil, max(pick, 0), 64);
       // repetition check over the last win_size emitted tokens (utils/common.py:111-113)
       const int rep = __popcll(__ballot(recent_ok && recent == tok));
+      const bool repeated = (float)rep >= (float)p.win_size * p.tau_r;
+      int tok_out = tok;
+      if (repeated && p.fallback_mode == 1) {   // second nucleus draw over the wider prefix (common.py:121-122)
+        const float target2 = u2 * cum2;
+        float c2 = 0.f;
+        int pick2 = ncand2 - 1;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+          if (i >= ncand2) break;
+          c2 += lane_bcast(cpl2, i);
+          if (c2 > target2) { pick2 = i; break; }
+        }
+        tok_out = __shfl(cil2, max(pick2, 0), 64);
+      }
       if (lane == 0) {
-        s_flag[0] = ((float)rep >= (float)p.win_size * p.tau_r) ? 1 : 0;
-        s_flag[1] = tok;
+        s_flag[0] = (repeated && p.fallback_mode == 0) ? 1 : 0;
+        s_flag[1] = tok_out;
         s_u2 = u2;
       }
     }

@@ -54,33 +54,38 @@ class UpsampleConformerEncoder:
     def output_size(self):
         return self.cfg.enc_dim
 
+    def _load_layer(self, P, sd, name):
+        """One ConformerEncoderLayer (rel-pos self-attention + FFN, no cnn module, no macaron): packed operands."""
+        a = f"{name}.self_attn."
+        bq = sd[a + "linear_q.bias"].float()
+        wq = sd[a + "linear_q.weight"].float()
+        wqqk = torch.cat([wq, wq, sd[a + "linear_k.weight"].float()], 0)
+        bqqk = torch.cat([bq + sd[a + "pos_bias_u"].float().reshape(-1), bq + sd[a + "pos_bias_v"].float().reshape(-1),
+                          sd[a + "linear_k.bias"].float()], 0)
+        # softmax rows sum to 1, so P.(V + 1 b_v^T) = P.V + b_v: the value bias is folded into linear_out's bias
+        wout = sd[a + "linear_out.weight"].float()
+        bout = sd[a + "linear_out.bias"].float() + wout @ sd[a + "linear_v.bias"].float()
+        return dict(wqqk=wqqk.to(device=self.device, dtype=self.dtype).contiguous(),
+                    bqqk=bqqk.to(device=self.device).contiguous(), wv=P.w(a + "linear_v.weight"),
+                    wpos=P.w(a + "linear_pos.weight"), wout=P.w(a + "linear_out.weight"),
+                    bout=bout.to(device=self.device).contiguous(),
+                    w1=P.w(f"{name}.feed_forward.w_1.weight"), b1=P.f32(f"{name}.feed_forward.w_1.bias"),
+                    w2=P.w(f"{name}.feed_forward.w_2.weight"), b2=P.f32(f"{name}.feed_forward.w_2.bias"),
+                    g_mha=P.f32(f"{name}.norm_mha.weight"), b_mha=P.f32(f"{name}.norm_mha.bias"),
+                    g_ff=P.f32(f"{name}.norm_ff.weight"), b_ff=P.f32(f"{name}.norm_ff.bias"))
+
+    @staticmethod
+    def _load_embed(P, name):
+        return dict(w=P.w(f"{name}.out.0.weight"), b=P.f32(f"{name}.out.0.bias"), g=P.f32(f"{name}.out.1.weight"),
+                    beta=P.f32(f"{name}.out.1.bias"))
+
     def load(self, sd, prefix="encoder."):
         cfg = self.cfg
         P = _P(sd, self.dtype, self.device)
         D = cfg.enc_dim
 
-        def layer(name):
-            a = f"{name}.self_attn."
-            bq = sd[a + "linear_q.bias"].float()
-            wq = sd[a + "linear_q.weight"].float()
-            wqqk = torch.cat([wq, wq, sd[a + "linear_k.weight"].float()], 0)
-            bqqk = torch.cat([bq + sd[a + "pos_bias_u"].float().reshape(-1), bq + sd[a + "pos_bias_v"].float().reshape(-1),
-                              sd[a + "linear_k.bias"].float()], 0)
-            # softmax rows sum to 1, so P.(V + 1 b_v^T) = P.V + b_v: the value bias is folded into linear_out's bias
-            wout = sd[a + "linear_out.weight"].float()
-            bout = sd[a + "linear_out.bias"].float() + wout @ sd[a + "linear_v.bias"].float()
-            return dict(wqqk=wqqk.to(device=self.device, dtype=self.dtype).contiguous(),
-                        bqqk=bqqk.to(device=self.device).contiguous(), wv=P.w(a + "linear_v.weight"),
-                        wpos=P.w(a + "linear_pos.weight"), wout=P.w(a + "linear_out.weight"),
-                        bout=bout.to(device=self.device).contiguous(),
-                        w1=P.w(f"{name}.feed_forward.w_1.weight"), b1=P.f32(f"{name}.feed_forward.w_1.bias"),
-                        w2=P.w(f"{name}.feed_forward.w_2.weight"), b2=P.f32(f"{name}.feed_forward.w_2.bias"),
-                        g_mha=P.f32(f"{name}.norm_mha.weight"), b_mha=P.f32(f"{name}.norm_mha.bias"),
-                        g_ff=P.f32(f"{name}.norm_ff.weight"), b_ff=P.f32(f"{name}.norm_ff.bias"))
-
-        def emb(name):
-            return dict(w=P.w(f"{name}.out.0.weight"), b=P.f32(f"{name}.out.0.bias"), g=P.f32(f"{name}.out.1.weight"),
-                        beta=P.f32(f"{name}.out.1.bias"))
+        layer = lambda name: self._load_layer(P, sd, name)
+        emb = lambda name: self._load_embed(P, name)
 
         self.embed = emb(prefix + "embed")
         self.up_embed = emb(prefix + "up_embed")

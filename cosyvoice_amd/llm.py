@@ -42,6 +42,9 @@ class Qwen2LM:
         assert max_batch <= 16 and ctx_max % 64 == 0
         self.max_batch, self.ctx_max, self.max_out = max_batch, ctx_max, max_out
         self.top_p, self.top_k, self.win_size, self.tau_r = top_p, top_k, win_size, tau_r
+        # repetition fallback of the sampler: 0 = ras_sampling (random over the full distribution, utils/common.py:106-112),
+        # 1 = non_random_ras_sampling (:116-123): nucleus again with (top_p2, top_k2) = (top_p + 0.15, top_k * expand_scale)
+        self.fallback_mode, self.top_p2, self.top_k2 = 0, 0.0, 0
         self.speech_token_size = self.cfg.speech_token_size
         self.sos_eos, self.task_id = 0, 1
         self.fp16 = False
@@ -139,6 +142,7 @@ class Qwen2LM:
         p.logits, p.ldl, p.V, p.B = st["logits"].data_ptr(), self.Vpad, cfg.out_vocab, B
         p.eos, p.top_k, p.top_p, p.win_size, p.tau_r = cfg.speech_token_size, self.top_k, self.top_p, self.win_size, self.tau_r
         p.seed = self.seed
+        p.fallback_mode, p.top_p2, p.top_k2 = self.fallback_mode, self.top_p2, self.top_k2
         p.uniforms = st["uniforms"].data_ptr() if use_uniforms else None
         p.max_trials = 100
         p.min_len, p.max_len = st["min_len"].data_ptr(), st["max_len"].data_ptr()
@@ -194,7 +198,7 @@ class Qwen2LM:
         if not self.use_graph:
             self._decode_step(B, use_forced, use_uniforms)
             return
-        key = (B, use_forced, use_uniforms, self.seed, self.cu_budget)
+        key = (B, use_forced, use_uniforms, self.seed, self.cu_budget, self.top_p, self.top_k, self.fallback_mode, self.top_p2, self.top_k2)
         g = self._graphs.get(key)
         if g is None:
             g = ops.Graph().capture(lambda: self._decode_step(B, use_forced, use_uniforms))
@@ -357,14 +361,15 @@ class Qwen2LM:
 
     @torch.no_grad()
     def inference(self, text, text_len, prompt_text, prompt_text_len, prompt_speech_token, prompt_speech_token_len, embedding,
-                  sampling: int = 25, max_token_text_ratio: float = 20, min_token_text_ratio: float = 2
-                  ) -> Generator[int, None, None]:
-        """Reference signature (llm.py:823-836).  Yields python ints as they become available (polled every 8 steps)."""
+                  sampling: int = 25, max_token_text_ratio: float = 20, min_token_text_ratio: float = 2,
+                  lm_input: Optional[torch.Tensor] = None) -> Generator[int, None, None]:
+        """Reference signature (llm.py:823-836).  Yields python ints as they become available (polled every 8 steps).
+        ``lm_input`` (L, hidden): a ready-made prefill embedding sequence (see generate_batch)."""
         assert self._loaded
         text_len += prompt_text_len  # the reference mutates text_len in place (llm.py:839)
         st = self.st
         B = 1
-        Lp = 1 + prompt_text.numel() + text.numel() + 1 + prompt_speech_token.numel()
+        Lp = int(lm_input.shape[0]) if lm_input is not None else 1 + prompt_text.numel() + text.numel() + 1 + prompt_speech_token.numel()
         ws = self._prefill_workspace(B, Lp)
         for k in ("step", "n_emitted", "finished"):
             st[k].zero_()
@@ -375,7 +380,7 @@ class Qwen2LM:
             raise ValueError("ctx_max too small for this request")
         st["min_len"].fill_(min_len)
         st["max_len"].fill_(max_len)
-        self._assemble_inputs(ws, [text], [prompt_text], [prompt_speech_token], B, Lp)
+        self._assemble(ws, [text], [prompt_text], [prompt_speech_token], B, Lp, None if lm_input is None else [lm_input])
         self._prefill(B, Lp, False, False)
         sent, steps = 0, 1
         while True:

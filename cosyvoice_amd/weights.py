@@ -333,3 +333,36 @@ def bigvgan_specs(cfg) -> List[Spec]:
 
 def bigvgan_state_dict(cfg, seed: int = 0, round_to=None) -> Dict[str, torch.Tensor]:
     return materialize(bigvgan_specs(cfg), seed, round_to)
+
+
+# --------------------------------------------------------------------------- Qwen2LM_Phoneme_Src2
+def phoneme_lm_specs(pcfg, lcfg: LlmConfig) -> List[Spec]:
+    """llm.py:1482-1531 module tree: text_embedding.{0..3}, text_encoder (ConformerEncoder), text_encoder_affine_layer,
+    src_attention.0 (DecoderLayer), spk_embed_affine_layer + the Qwen2 stack / llm_embedding / llm_decoder / speech_embedding."""
+    s: List[Spec] = llm_specs(lcfg)
+    H, D = lcfg.hidden_size, pcfg.enc_dim
+    for i, (n, d) in enumerate(((pcfg.text_token_size, pcfg.text_token_dim), (pcfg.text_tone_size, pcfg.text_tone_dim),
+                                (pcfg.text_lang_size, pcfg.text_lang_dim), (pcfg.text_prsd_size, pcfg.text_prsd_dim))):
+        s.append((f"text_embedding.{i}.weight", (n, d), "normal", 1.0))
+    _linear(s, "text_encoder.embed.out.0", D, pcfg.input_size)
+    _ln(s, "text_encoder.embed.out.1", D)
+    _ln(s, "text_encoder.after_norm", D)
+    for i in range(pcfg.enc_blocks):
+        _conformer_layer(s, f"text_encoder.encoders.{i}", D, pcfg.enc_heads, pcfg.enc_linear_units)
+    _linear(s, "text_encoder_affine_layer", H, D)
+    for att in ("self_attn", "src_attn"):
+        for lin in ("linear_q", "linear_k", "linear_v", "linear_out"):
+            _linear(s, f"src_attention.0.{att}.{lin}", H, H, gain=(0.5 if lin == "linear_out" else 1.0))
+    _linear(s, "src_attention.0.feed_forward.w_1", pcfg.src_linear_units, H)
+    _linear(s, "src_attention.0.feed_forward.w_2", H, pcfg.src_linear_units, gain=0.5)
+    for n in ("norm1", "norm2", "norm3"):
+        _ln(s, f"src_attention.0.{n}", H)
+    _linear(s, "spk_embed_affine_layer", H, pcfg.spk_embed_dim)
+    return s
+
+
+def phoneme_lm_state_dict(pcfg, lcfg: LlmConfig, seed: int = 1986, round_to=None):
+    sd = materialize(phoneme_lm_specs(pcfg, lcfg), seed, round_to)
+    if lcfg.tie_word_embeddings:
+        sd["llm.model.lm_head.weight"] = sd["llm.model.model.embed_tokens.weight"]
+    return sd

@@ -241,6 +241,9 @@ typedef struct cv_sample_params {
   const float* logits; int32_t ldl; int32_t V; int32_t B;
   int32_t eos; int32_t top_k; float top_p; int32_t win_size; float tau_r;
   uint64_t seed;
+  /* repetition fallback: 0 = random_sampling over the full distribution (ras_sampling, utils/common.py:106-112);
+     1 = a second nucleus draw with (top_p2, top_k2) (non_random_ras_sampling :116-123: top_p + 0.15, top_k * expand_scale) */
+  int32_t fallback_mode; float top_p2; int32_t top_k2;
   const float* uniforms;      /* optional [B][max_trials+1][2] injected uniforms (tests); null -> Philox */
   int32_t max_trials;
   const int32_t* min_len; const int32_t* max_len;   /* [B] */

@@ -410,11 +410,75 @@ def golden_frontend_mel():
     save("frontend_mel", y=y, mel=mel)
 
 
+def golden_llm_phoneme():
+    """Qwen2LM_Phoneme_Src2 (llm/llm.py:1450-1772), the LM every recipe of the fork uses: the reference module itself
+    (reference ConformerEncoder text encoder, reference DecoderLayer, HF Qwen2 from a config-only directory) run up to the
+    first forward_one_step call; the prefill embedding sequence lm_input it hands to the Qwen2 stack is the golden."""
+    from cosyvoice_amd.config import LlmConfig, PhonemeFrontConfig
+    from cosyvoice_amd.weights import phoneme_lm_state_dict
+    from cosyvoice.llm.llm import Qwen2Encoder, Qwen2LM_Phoneme_Src2
+    from cosyvoice.transformer.encoder import ConformerEncoder
+    from cosyvoice.utils.common import non_random_ras_sampling
+    lc, pc = LlmConfig.tiny(), PhonemeFrontConfig.tiny()
+    sd = phoneme_lm_state_dict(pc, lc, seed=31)
+    with tempfile.TemporaryDirectory() as d:
+        json.dump(lc.hf_config_dict(), open(os.path.join(d, "config.json"), "w"))
+        enc = ConformerEncoder(input_size=pc.input_size, output_size=pc.enc_dim, attention_heads=pc.enc_heads,
+                               linear_units=pc.enc_linear_units, num_blocks=pc.enc_blocks, dropout_rate=0.1,
+                               positional_dropout_rate=0.1, attention_dropout_rate=0.0, normalize_before=True, input_layer="linear",
+                               pos_enc_layer_type="rel_pos_espnet", selfattention_layer_type="rel_selfattn", use_cnn_module=False,
+                               macaron_style=False, use_dynamic_chunk=False, use_dynamic_left_chunk=False, static_chunk_size=-1)
+        m = Qwen2LM_Phoneme_Src2(text_encoder_input_size=pc.input_size, llm_input_size=lc.hidden_size, llm_output_size=lc.hidden_size,
+                                 text_token_size=pc.text_token_size, text_token_dim=pc.text_token_dim, text_tone_size=pc.text_tone_size,
+                                 text_tone_dim=pc.text_tone_dim, text_lang_size=pc.text_lang_size, text_lang_dim=pc.text_lang_dim,
+                                 text_prsd_size=pc.text_prsd_size, text_prsd_dim=pc.text_prsd_dim,
+                                 speech_token_size=lc.speech_token_size, text_encoder=enc, llm=Qwen2Encoder(d),
+                                 sampling=non_random_ras_sampling, spk_embed_dim=pc.spk_embed_dim)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all("rotary" in k or "inv_freq" in k for k in missing), (missing, unexpected)
+    m.eval()
+    g = torch.Generator().manual_seed(17)
+    L, P, Lp, Pp, N = 6, 11, 3, 5, 7
+
+    def pho_ids(n):
+        return torch.stack([torch.randint(0, pc.text_token_size, (1, n), generator=g), torch.randint(0, pc.text_tone_size, (1, n), generator=g),
+                            torch.randint(0, pc.text_lang_size, (1, n), generator=g), torch.randint(0, pc.text_prsd_size, (1, n), generator=g)], dim=-1)
+
+    text = torch.randint(0, lc.vocab_size, (1, L), generator=g)
+    ptext = torch.randint(0, lc.vocab_size, (1, Lp), generator=g)
+    pho, ppho = pho_ids(P), pho_ids(Pp)
+    pspeech = torch.randint(0, lc.speech_token_size, (1, N), generator=g)
+    emb = torch.randn(1, pc.spk_embed_dim, generator=g)
+    captured = {}
+    orig = m.llm.forward_one_step
+
+    class _Stop(Exception):
+        pass
+
+    def spy(xs, masks, cache=None):
+        captured["lm_input"] = xs.detach().clone()
+        raise _Stop()
+
+    m.llm.forward_one_step = spy
+    try:
+        with torch.inference_mode():
+            next(m.inference(text=(text, pho), text_len=(torch.tensor([L]), torch.tensor([P])), prompt_text=(ptext, ppho),
+                             prompt_text_len=(torch.tensor([Lp]), torch.tensor([Pp])), prompt_speech_token=pspeech,
+                             prompt_speech_token_len=torch.tensor([N]), embedding=emb))
+    except (_Stop, RuntimeError) as e:   # a generator converts the exception of its body into RuntimeError
+        if "lm_input" not in captured:
+            raise e
+    m.llm.forward_one_step = orig
+    save("llm_phoneme_tiny", text=text.to(torch.int32), pho=pho.to(torch.int32), prompt_text=ptext.to(torch.int32),
+         prompt_pho=ppho.to(torch.int32), prompt_speech_token=pspeech.to(torch.int32), embedding=emb,
+         lm_input=captured["lm_input"], seed=np.array(31))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     install_stubs()
-    which = sys.argv[1:] or ["hift", "flow", "llm", "bigvgan", "frontend"]
+    which = sys.argv[1:] or ["hift", "flow", "llm", "bigvgan", "frontend", "phoneme"]
     if "hift" in which:
         golden_hift()
     if "flow" in which:
@@ -426,6 +490,8 @@ def main():
         golden_bigvgan_model()
     if "frontend" in which:
         golden_frontend_mel()
+    if "phoneme" in which:
+        golden_llm_phoneme()
 
 
 if __name__ == "__main__":

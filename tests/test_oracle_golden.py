@@ -153,3 +153,17 @@ def test_frontend_mel_vs_reference(golden_dir):
     assert f.shape[1] == 100 and int(fl) == 100 and t.shape[1] == 50 and int(tl) == 50
     f, fl, t, tl = align_prompt_24k(torch.zeros(1, 100, 80), torch.zeros(1, 37, dtype=torch.int32))
     assert f.shape[1] == 74 and t.shape[1] == 37
+
+
+def test_phoneme_lm_front_end_vs_reference(golden_dir):
+    """oracle.llm_phoneme.phoneme_lm_input against the lm_input the reference's Qwen2LM_Phoneme_Src2.inference hands to its
+    Qwen2 stack (golden minted by make_golden.py from the reference module itself)."""
+    from cosyvoice_amd.config import LlmConfig, PhonemeFrontConfig
+    from cosyvoice_amd.weights import phoneme_lm_state_dict
+    from oracle import llm_phoneme as op
+    g = _load(golden_dir, "llm_phoneme_tiny")
+    lc, pc = LlmConfig.tiny(), PhonemeFrontConfig.tiny()
+    sd = phoneme_lm_state_dict(pc, lc, seed=int(g["seed"]))
+    x = op.phoneme_lm_input(sd, pc, lc, g["text"], g["pho"], g["prompt_text"], g["prompt_pho"], g["prompt_speech_token"], g["embedding"])
+    assert x.shape == g["lm_input"].shape
+    assert (x - g["lm_input"]).abs().max().item() < 1e-5
