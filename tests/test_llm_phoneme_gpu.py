@@ -122,3 +122,30 @@ def test_reference_signature_generator():
                             prompt_speech_token=e_i, prompt_speech_token_len=torch.tensor([0], dtype=torch.int32),
                             embedding=torch.randn(1, pc.spk_embed_dim, generator=g)))
     assert 2 * L <= len(toks) <= 20 * L and all(isinstance(t, int) and 0 <= t < lc.speech_token_size for t in toks)
+
+
+def test_lm_input_reference_dimensions_vs_oracle():
+    """The production dimensions of the front-end (phoneme factors 400+64+16+32, 6 x 1024-wide conformer layers with 16 heads,
+    DecoderLayer over hidden 896 = 16 heads x 56 channels, zero-padded to the kernel's 64-wide heads, FFN 4096) on a 1-layer
+    Qwen2 of hidden size 896, against the oracle."""
+    import dataclasses
+    from cosyvoice_amd.llm_phoneme import Qwen2LM_Phoneme_Src2
+    from oracle import llm_phoneme as op
+    lc = dataclasses.replace(LlmConfig.tiny(), hidden_size=896, num_heads=14, num_kv_heads=2, num_layers=1)
+    pc = PhonemeFrontConfig.full()
+    sd = phoneme_lm_state_dict(pc, lc, seed=8)
+    m = Qwen2LM_Phoneme_Src2(lc, pc, dtype=torch.float16, max_batch=2, ctx_max=256, max_out=64).load_state_dict(sd)
+    g = torch.Generator().manual_seed(6)
+    L, P_, N = 12, 41, 9
+    pho = torch.stack([torch.randint(0, n, (1, P_), generator=g) for n in (pc.text_token_size, pc.text_tone_size, pc.text_lang_size,
+                                                                           pc.text_prsd_size)], dim=-1)
+    text = torch.randint(0, lc.vocab_size, (1, L), generator=g)
+    ps = torch.randint(0, lc.speech_token_size, (1, N), generator=g)
+    emb = torch.randn(1, pc.spk_embed_dim, generator=g)
+    e_i, e_p = torch.zeros(1, 0, dtype=torch.int64), torch.zeros(1, 0, 4, dtype=torch.int64)
+    ref = op.phoneme_lm_input(sd, pc, lc, text, pho, e_i, e_p, ps, emb)[0]
+    x = m.lm_input(text, pho, e_i, e_p, ps, emb).cpu()
+    err = (x - ref).abs()
+    print(f"lm_input full dims: Linf {err.max().item():.3e} L1 {err.mean().item():.3e} (|ref| max {ref.abs().max().item():.2f})")
+    assert x.shape == ref.shape == (1 + 1 + P_ + 1 + N, 896)
+    assert err.max().item() < 3e-2 and err.mean().item() < 3e-3
