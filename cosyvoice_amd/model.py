@@ -70,12 +70,21 @@ class CosyVoice2Model:
         return self
 
     def llm_job(self, text, prompt_text, llm_prompt_speech_token, llm_embedding, uuid_):
-        # model.py:116-128
+        # model.py:116-128.  The fork's phoneme LMs (Qwen2LM_Phoneme_Src2.inference, llm.py:1687-1699) take
+        # text = (bpe ids, phoneme factors) and matching length tuples: tuples are passed through in that form.
+        dev = self.device
+        if isinstance(text, (tuple, list)):
+            to = lambda t: tuple(x.to(dev) for x in t)
+            ln = lambda t: tuple(torch.tensor([x.shape[1]], dtype=torch.int32) for x in t)
+            text_a, text_len, ptext_a, ptext_len = to(text), ln(text), to(prompt_text), ln(prompt_text)
+        else:
+            text_a, text_len = text.to(dev), torch.tensor([text.shape[1]], dtype=torch.int32)
+            ptext_a, ptext_len = prompt_text.to(dev), torch.tensor([prompt_text.shape[1]], dtype=torch.int32)
         with self.llm_context:
-            for i in self.llm.inference(text=text.to(self.device),
-                                        text_len=torch.tensor([text.shape[1]], dtype=torch.int32),
-                                        prompt_text=prompt_text.to(self.device),
-                                        prompt_text_len=torch.tensor([prompt_text.shape[1]], dtype=torch.int32),
+            for i in self.llm.inference(text=text_a,
+                                        text_len=text_len,
+                                        prompt_text=ptext_a,
+                                        prompt_text_len=ptext_len,
                                         prompt_speech_token=llm_prompt_speech_token.to(self.device),
                                         prompt_speech_token_len=torch.tensor([llm_prompt_speech_token.shape[1]], dtype=torch.int32),
                                         embedding=llm_embedding):

@@ -149,3 +149,35 @@ def test_lm_input_reference_dimensions_vs_oracle():
     print(f"lm_input full dims: Linf {err.max().item():.3e} L1 {err.mean().item():.3e} (|ref| max {ref.abs().max().item():.2f})")
     assert x.shape == ref.shape == (1 + 1 + P_ + 1 + N, 896)
     assert err.max().item() < 3e-2 and err.mean().item() < 3e-3
+
+
+def test_orchestrator_with_phoneme_lm_end_to_end():
+    """CosyVoice2Model(Qwen2LM_Phoneme_Src2, flow, hift).tts with text = (bpe ids, phoneme factors): the LLM thread, flow and
+    HiFT run end to end and yield a finite waveform of 2 * hop samples per generated token."""
+    from cosyvoice_amd.config import FlowConfig, HiftConfig
+    from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
+    from cosyvoice_amd.hift import HiFTGenerator
+    from cosyvoice_amd.llm_phoneme import Qwen2LM_Phoneme_Src2
+    from cosyvoice_amd.model import CosyVoice2Model
+    from cosyvoice_amd.weights import flow_state_dict, hift_state_dict
+    lc, pc, fc, hc = LlmConfig.tiny(), PhonemeFrontConfig.tiny(), FlowConfig.tiny(), HiftConfig.tiny()
+    llm = Qwen2LM_Phoneme_Src2(lc, pc, dtype=torch.bfloat16, max_batch=2, ctx_max=256, max_out=256)
+    llm.load_state_dict(phoneme_lm_state_dict(pc, lc, seed=5, round_to=torch.bfloat16))
+    flow = CausalMaskedDiffWithXvec(fc, dtype=torch.float16).load_state_dict(flow_state_dict(fc))
+    hift = HiFTGenerator(hc, dtype=torch.float32).load_state_dict(hift_state_dict(hc))
+    m = CosyVoice2Model(llm, flow, hift)
+    g = torch.Generator().manual_seed(12)
+    L, P_, n_p = 4, 9, 6
+    pho = torch.stack([torch.randint(0, n, (1, P_), generator=g) for n in (pc.text_token_size, pc.text_tone_size, pc.text_lang_size,
+                                                                           pc.text_prsd_size)], dim=-1)
+    text = torch.randint(0, lc.vocab_size, (1, L), generator=g)
+    e_i, e_p = torch.zeros(1, 0, dtype=torch.int64), torch.zeros(1, 0, 4, dtype=torch.int64)
+    ptok = torch.randint(0, lc.speech_token_size, (1, n_p), generator=g, dtype=torch.int32)
+    pfeat = torch.clamp(torch.randn(1, 2 * n_p, 80, generator=g) * 2 - 6, -11.5, 2.0)
+    out = list(m.tts(text=(text, pho), flow_embedding=torch.randn(1, fc.spk_embed_dim, generator=g),
+                     llm_embedding=torch.randn(1, pc.spk_embed_dim, generator=g), prompt_text=(e_i, e_p),
+                     llm_prompt_speech_token=ptok, flow_prompt_speech_token=ptok, prompt_speech_feat=pfeat, stream=False))
+    assert len(out) == 1
+    wav = out[0]["tts_speech"]
+    n = wav.shape[1] // (2 * hc.total_upsample)
+    assert wav.shape == (1, n * 2 * hc.total_upsample) and 2 * L <= n <= 20 * L and torch.isfinite(wav).all()
