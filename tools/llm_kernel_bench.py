@@ -62,9 +62,9 @@ def bench(name, fn, per_rep, configs):
     CAP = 0
     print(f"{name:10s} " + "  ".join(f"{t:6.2f} us" for t in out), flush=True)
 
-full, part = torch.cuda.current_stream(), ops.masked_stream(lambda s_, x_: s_ < 13)
-configs = [(full, 0), (part, 0), (part, 104), (part, 208)]
-print("kernel      all CUs | 104 CUs, max_wgs = 0 / 104 / 208")
+full, part = torch.cuda.current_stream(), ops.masked_stream(lambda s_, x_: s_ < 8)
+configs = [(full, 0), (part, 0)]
+print("kernel      all CUs | 64 CUs")
 only = __import__('os').environ.get('LKB_ONLY')
 for name, fn, per in (("qkv", k_qkv, 24), ("attn", k_attn, 24), ("o_proj", k_o, 24), ("gate_up", k_gu, 24), ("gu_nonorm", k_gu_nonorm, 24), ("down", k_down, 24),
                       ("final_norm", k_final, 24), ("head", k_head, 24)):
