@@ -25,7 +25,8 @@ def fade_in_out(fade_in_mel, fade_out_mel, window):
     device = fade_in_mel.device
     fade_in_mel, fade_out_mel = fade_in_mel.cpu().clone(), fade_out_mel.cpu()
     n = int(window.shape[0] / 2)
-    fade_in_mel[..., :n] = fade_in_mel[..., :n] * window[:n] + fade_out_mel[..., -n:] * window[n:]
+    w = torch.as_tensor(window)   # float64 hamming window, as the reference's numpy broadcast (result is cast back on assignment)
+    fade_in_mel[..., :n] = fade_in_mel[..., :n] * w[:n] + fade_out_mel[..., -n:] * w[n:]
     return fade_in_mel.to(device)
 
 
@@ -328,3 +329,121 @@ class CosyVoice2Model:
             if toks is not None:
                 torch.cuda.current_stream().wait_event(ready)  # conditioning of this batch is in place
                 pending = self._flow_hift(b, toks)
+
+
+class CosyVoiceModel(CosyVoice2Model):
+    """Drop-in for the reference's ``CosyVoiceModel`` (/root/reference/cosyvoice/cli/model.py:27-292) — the v1 wiring, which
+    the fork also drives CosyVoice2 modules with (bin/inference_online_codec.py): the estimator attends over the whole
+    sequence (``static_chunk_size = 0``, :49-50; the encoder's chunk size is left alone), streaming works on hop-sized
+    token windows with ``token_overlap_len`` = 20 tokens of overlap (every chunk sees only the prompt and its own window, the
+    consumed tokens are dropped), consecutive mels are cross-faded over ``mel_overlap_len`` frames and the vocoder keeps a
+    20-frame mel / source / speech cache (:52-60, :130-172).  ``vc`` feeds source speech tokens instead of running the LLM."""
+
+    def __init__(self, llm, flow, hift, fp16: bool = False, sr: int = 22050):
+        super().__init__(llm, flow, hift, fp16)
+        self.sample_rate = sr
+        self.flow.encoder.static_chunk_size = 0              # CosyVoice2Model.__init__ set 2 * frame rate; v1 never does
+        self.flow.decoder.estimator.static_chunk_size = 0    # model.py:49-50
+        self.token_min_hop_len = 2 * self.flow.input_frame_rate
+        self.token_max_hop_len = 4 * self.flow.input_frame_rate
+        self.token_overlap_len = 20
+        self.mel_overlap_len = int(self.token_overlap_len / self.flow.input_frame_rate * sr / 256)
+        self.mel_window = np.hamming(2 * self.mel_overlap_len)
+        self.mel_cache_len = 20
+        self.source_cache_len = int(self.mel_cache_len * 256)
+        self.speech_window = np.hamming(2 * self.source_cache_len)
+        self.mel_overlap_dict = {}
+        self.flow_cache_dict = {}
+
+    def token2wav(self, token, prompt_token=torch.zeros(1, 0, dtype=torch.int32), prompt_feat=torch.zeros(1, 0, 80),
+                  embedding=torch.zeros(0, 512), uuid_="0", finalize=False, speed=1.0):
+        # model.py:130-172
+        n = lambda t: torch.tensor([t.shape[1]], dtype=torch.int32)
+        mel, self.flow_cache_dict[uuid_] = self.flow.inference(
+            token=token.to(self.device), token_len=n(token), prompt_token=prompt_token.to(self.device), prompt_token_len=n(prompt_token),
+            prompt_feat=prompt_feat.to(self.device), prompt_feat_len=n(prompt_feat), embedding=embedding.to(self.device),
+            flow_cache=self.flow_cache_dict[uuid_], sample_rate=self.sample_rate)
+        if self.mel_overlap_dict[uuid_].shape[2] != 0:
+            mel = fade_in_out(mel, self.mel_overlap_dict[uuid_], self.mel_window)
+        cache = self.hift_cache_dict[uuid_]
+        cache_source = torch.zeros(1, 1, 0)
+        if cache is not None:
+            mel = torch.concat([cache["mel"], mel], dim=2)
+            cache_source = cache["source"]
+        if not finalize:
+            self.mel_overlap_dict[uuid_] = mel[:, :, -self.mel_overlap_len:].clone()
+            mel = mel[:, :, :-self.mel_overlap_len]
+            speech, source = self.hift.inference(speech_feat=mel, cache_source=cache_source)
+            speech, source = speech.clone(), source.clone()
+            if cache is not None:
+                speech = fade_in_out(speech, cache["speech"], self.speech_window)
+            self.hift_cache_dict[uuid_] = {"mel": mel[:, :, -self.mel_cache_len:].clone(),
+                                           "source": source[:, :, -self.source_cache_len:].clone(),
+                                           "speech": speech[:, -self.source_cache_len:].clone()}
+            return speech[:, :-self.source_cache_len]
+        if speed != 1.0:
+            assert cache is None, "speed change only support non-stream inference mode"
+            mel = F.interpolate(mel, size=int(mel.shape[2] / speed), mode="linear")
+        speech, _ = self.hift.inference(speech_feat=mel, cache_source=cache_source)
+        speech = speech.clone()
+        if cache is not None:
+            speech = fade_in_out(speech, cache["speech"], self.speech_window)
+        return speech
+
+    def _open(self, uuid_, tokens, ended):
+        with self.lock:
+            self.tts_speech_token_dict[uuid_], self.llm_end_dict[uuid_] = tokens, ended
+            self.hift_cache_dict[uuid_] = None
+            self.mel_overlap_dict[uuid_] = torch.zeros(1, 80, 0)
+            self.flow_cache_dict[uuid_] = torch.zeros(1, 80, 0, 2)
+
+    def _close(self, uuid_):
+        with self.lock:
+            for d in (self.tts_speech_token_dict, self.llm_end_dict, self.mel_overlap_dict, self.hift_cache_dict, self.flow_cache_dict):
+                d.pop(uuid_, None)
+
+    def _emit(self, uuid_, producer, flow_prompt_speech_token, prompt_speech_feat, flow_embedding, stream, speed, poll):
+        """The token -> waveform schedule shared by tts (:173-238) and vc (:240-292): hop + overlap windows while streaming,
+        one pass over everything otherwise."""
+        kw = dict(prompt_token=flow_prompt_speech_token, prompt_feat=prompt_speech_feat, embedding=flow_embedding, uuid_=uuid_)
+        toks = lambda k=None: torch.tensor(self.tts_speech_token_dict[uuid_][:k]).unsqueeze(dim=0)
+        if stream:
+            hop = self.token_min_hop_len
+            while True:
+                if poll:
+                    time.sleep(poll)
+                if len(self.tts_speech_token_dict[uuid_]) >= hop + self.token_overlap_len:
+                    yield {"tts_speech": self.token2wav(token=toks(hop + self.token_overlap_len), finalize=False, **kw).cpu()}
+                    with self.lock:
+                        self.tts_speech_token_dict[uuid_] = self.tts_speech_token_dict[uuid_][hop:]
+                    hop = min(self.token_max_hop_len, int(hop * self.stream_scale_factor))
+                if self.llm_end_dict[uuid_] is True and len(self.tts_speech_token_dict[uuid_]) < hop + self.token_overlap_len:
+                    break
+            if producer is not None:
+                producer.join()
+            yield {"tts_speech": self.token2wav(token=toks(), finalize=True, **kw).cpu()}
+        else:
+            if producer is not None:
+                producer.join()
+            yield {"tts_speech": self.token2wav(token=toks(), finalize=True, speed=speed, **kw).cpu()}
+
+    def tts(self, text, flow_embedding, llm_embedding=torch.zeros(0, 512), prompt_text=torch.zeros(1, 0, dtype=torch.int32),
+            llm_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32), flow_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32),
+            prompt_speech_feat=torch.zeros(1, 0, 80), stream=False, speed=1.0, **kwargs):
+        this_uuid = str(uuid.uuid1())
+        self._open(this_uuid, [], False)
+        p = threading.Thread(target=self.llm_job, args=(text, prompt_text, llm_prompt_speech_token, llm_embedding, this_uuid))
+        p.start()
+        try:
+            yield from self._emit(this_uuid, p, flow_prompt_speech_token, prompt_speech_feat, flow_embedding, stream, speed, 0.1)
+        finally:
+            p.join()
+            self._close(this_uuid)
+
+    def vc(self, source_speech_token, flow_prompt_speech_token, prompt_speech_feat, flow_embedding, stream=False, speed=1.0, **kwargs):
+        this_uuid = str(uuid.uuid1())
+        self._open(this_uuid, source_speech_token.flatten().tolist(), True)
+        try:
+            yield from self._emit(this_uuid, None, flow_prompt_speech_token, prompt_speech_feat, flow_embedding, stream, speed, 0.0)
+        finally:
+            self._close(this_uuid)

@@ -474,11 +474,44 @@ def golden_llm_phoneme():
          lm_input=captured["lm_input"], seed=np.array(31))
 
 
+def golden_v1_orchestrator():
+    """Chunk schedule of the reference's CosyVoiceModel (v1 wiring, cli/model.py:27-292) driving CosyVoice2 modules, as the
+    fork does: vc() over 210 source tokens (a 60-token tail: the reference cross-fade needs the last chunk to hold at least mel_overlap_len = 68 frames), streaming and not — the number of samples of every yielded chunk (the waveforms
+    themselves carry the vocoder's random source phases and are not comparable)."""
+    from cosyvoice.cli.model import CosyVoiceModel
+    from cosyvoice_amd.config import FlowConfig, HiftConfig
+    from cosyvoice_amd.weights import flow_state_dict, hift_state_dict
+    fc, hc = FlowConfig.tiny(), HiftConfig.v1()
+    flow = build_ref_flow(fc, flow_state_dict(fc))
+    hift = build_ref_hift(hc, hift_state_dict(hc))
+
+    class _NoLLM(torch.nn.Module):
+        fp16 = False
+
+    m = CosyVoiceModel(_NoLLM(), flow, hift, fp16=False, sr=22050)
+    m.device = torch.device("cpu")
+    g = torch.Generator().manual_seed(99)
+    n_p = 12
+    src = torch.randint(0, fc.vocab_size, (1, 210), generator=g, dtype=torch.int32)
+    ptok = torch.randint(0, fc.vocab_size, (1, n_p), generator=g, dtype=torch.int32)
+    pfeat = torch.clamp(torch.randn(1, 2 * n_p, 80, generator=g) * 2 - 6, -11.5, 2.0)
+    emb = torch.randn(1, fc.spk_embed_dim, generator=g)
+    out = {}
+    for stream in (True, False):
+        torch.manual_seed(0)
+        with torch.inference_mode():
+            chunks = [o["tts_speech"] for o in m.vc(src, ptok, pfeat, emb, stream=stream)]
+        out["stream" if stream else "full"] = np.array([c.shape[1] for c in chunks], dtype=np.int64)
+        assert all(torch.isfinite(c).all() for c in chunks)
+    save("v1_orchestrator", source_speech_token=src, prompt_token=ptok, prompt_feat=pfeat, embedding=emb,
+         stream_chunk_samples=out["stream"], full_samples=out["full"])
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     install_stubs()
-    which = sys.argv[1:] or ["hift", "flow", "llm", "bigvgan", "frontend", "phoneme"]
+    which = sys.argv[1:] or ["hift", "flow", "llm", "bigvgan", "frontend", "phoneme", "v1orch"]
     if "hift" in which:
         golden_hift()
     if "flow" in which:
@@ -492,6 +525,8 @@ def main():
         golden_frontend_mel()
     if "phoneme" in which:
         golden_llm_phoneme()
+    if "v1orch" in which:
+        golden_v1_orchestrator()
 
 
 if __name__ == "__main__":

@@ -122,3 +122,35 @@ def test_tts_batch_free_running_ragged_lengths():
         n = w.numel() // (2 * hc.total_upsample)
         assert w.numel() == n * 2 * hc.total_upsample and 2 * i["text"].shape[1] <= n <= 20 * i["text"].shape[1]
         assert torch.isfinite(w).all() and w.abs().max() <= 0.99 + 1e-6
+
+
+@pytest.mark.gpu
+def test_v1_wiring_orchestrator_chunk_schedule(golden_dir):
+    """CosyVoiceModel (the v1 wiring the fork drives CosyVoice2 modules with): vc() streaming and not, against the chunk
+    lengths the reference's own CosyVoiceModel yields on the same inputs (golden); the non-stream waveform equals flow + HiFT
+    called directly."""
+    import os
+    import numpy as np
+    from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
+    from cosyvoice_amd.hift import HiFTGenerator
+    from cosyvoice_amd.model import CosyVoiceModel
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, "v1_orchestrator.npz")).items()}
+    fc, hc = FlowConfig.tiny(), HiftConfig.v1()
+    flow = CausalMaskedDiffWithXvec(fc, dtype=torch.float16).load_state_dict(flow_state_dict(fc))
+    hift = HiFTGenerator(hc, dtype=torch.float32).load_state_dict(hift_state_dict(hc))
+
+    class _NoLLM:
+        fp16 = False
+
+    m = CosyVoiceModel(_NoLLM(), flow, hift, fp16=False, sr=22050)
+    assert m.mel_overlap_len == 68 and m.token_min_hop_len == 50 and flow.decoder.estimator.static_chunk_size == 0
+    args = (g["source_speech_token"], g["prompt_token"], g["prompt_feat"], g["embedding"])
+    chunks = [o["tts_speech"] for o in m.vc(*args, stream=True)]
+    assert [c.shape[1] for c in chunks] == g["stream_chunk_samples"].tolist()
+    assert all(torch.isfinite(c).all() and c.abs().max() <= 0.99 + 1e-6 for c in chunks)
+    full = [o["tts_speech"] for o in m.vc(*args, stream=False)]
+    assert [c.shape[1] for c in full] == g["full_samples"].tolist()
+    assert not m.tts_speech_token_dict and not m.hift_cache_dict and not m.mel_overlap_dict   # per-request state released
+    # speed change (non-stream only, model.py:165-168): linear interpolation of the mel
+    fast = [o["tts_speech"] for o in m.vc(*args, stream=False, speed=2.0)]
+    assert fast[0].shape[1] == int(g["full_samples"][0]) // 2
