@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--flow-dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--llm-cu-slots", type=int, default=8,
                     help="CU slots per XCD (of 32) owned by the decode loops while they overlap flow+HiFT; 0 = no partition")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo only to rehearse the multi-process path with several ranks on ONE GPU")
     ap.add_argument("--llm-loops", type=int, default=2,
                     help="concurrent decode loops (one utterance batch each, own KV caches) on the decode CUs")
     args = ap.parse_args()
@@ -108,12 +110,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    local_rank %= torch.cuda.device_count()   # one rank per GPU; the modulo only matters for the gloo rehearsal on one GPU
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     from cosyvoice_amd.config import FlowConfig, HiftConfig, LlmConfig
     from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
