@@ -172,7 +172,7 @@ class UpsampleConformerEncoder:
         ops.layernorm(w["lin"].view(R * T, D), e["g"], e["beta"], 1e-5, out_scale=math.sqrt(D), out_f32=w["xs"].view(R * T, D),
                       out_act=w["xa"].view(R * T, D))
 
-    def forward_tokens(self, tok_emb_act, R, N, klen=None):
+    def forward_tokens(self, tok_emb_act, R, N, klen=None, n_valid=None):
         """tok_emb_act: (R,N,512) token embeddings in the operand dtype (already in ws['tok']).
         Returns ws (ws['b']['xa'] holds after_norm output, 16-bit, (R,2N,512)).  upsample_encoder.py:237-304."""
         cfg = self.cfg
@@ -180,6 +180,11 @@ class UpsampleConformerEncoder:
         ws = self._workspace(R, N)
         wa, wb = ws["a"], ws["b"]
         self._embed(self.embed, tok_emb_act.view(R * N, D), wa, R)
+        if n_valid is not None and n_valid < N:
+            # length-bucketed call: positions beyond the real sequence must read as the zero padding the look-ahead conv of the
+            # reference sees beyond the end (upsample_encoder.py:81-88); everything after it only looks left or is masked by klen
+            wa["xs"][:, n_valid:].zero_()
+            wa["xa"][:, n_valid:].zero_()
         # PreLookaheadLayer (upsample_encoder.py:81-96): conv k4 looking right (zero beyond the end), leaky 0.01,
         # conv k3 looking left, residual
         ops.conv1d_cl(wa["xa"], self.pl1_w, cfg.pre_lookahead_len + 1, pad_left=0, bias=self.pl1_b, act=ops.ACT_LEAKY,
@@ -420,7 +425,14 @@ class CausalConditionalCFM:
         ws = est._workspace(R, T)
         ts, dts = self.schedule(n_timesteps)
         tt = est.time_table(ts)
-        klen2 = klen.repeat_interleave(2) if klen is not None else None
+        klen2 = None
+        if klen is not None:   # persistent buffer: its address is baked into the captured graph, its contents change per call
+            if not hasattr(self, "_klen2"):
+                self._klen2 = {}
+            klen2 = self._klen2.get(B)
+            if klen2 is None:
+                klen2 = self._klen2[B] = torch.zeros(2 * B, device=x.device, dtype=torch.int32)
+            klen2.copy_(klen.repeat_interleave(2))
 
         def run():
             for i in range(n_timesteps):
@@ -503,7 +515,9 @@ class CausalMaskedDiffWithXvec:
                                    spks=torch.empty(B, self.cfg.output_size, device=dev),
                                    cond=torch.zeros(B, 2 * N, self.cfg.output_size, device=dev),
                                    x=torch.empty(B, 2 * N, self.cfg.output_size, device=dev),
-                                   mel=torch.empty(B, self.cfg.output_size, 2 * N, device=dev))
+                                   mel=torch.empty(B, self.cfg.output_size, 2 * N, device=dev),
+                                   klen_enc=torch.zeros(B, device=dev, dtype=torch.int32),
+                                   klen_est=torch.zeros(B, device=dev, dtype=torch.int32))
         return self._bufs[key]
 
     @torch.no_grad()
@@ -515,7 +529,14 @@ class CausalMaskedDiffWithXvec:
         cfg, dev = self.cfg, self.device
         B, Ng = tokens.shape
         Np = prompt_tokens.shape[1]
-        N = Np + Ng
+        Nv = Np + Ng                       # real tokens
+        # length bucketing (off by default): run at the next multiple of ``length_bucket`` tokens with the tail masked, so a
+        # stream of requests of arbitrary lengths re-uses a handful of captured estimator graphs instead of capturing one per
+        # length (339 ms instead of 138 ms to the first chunk, tools/stream_latency.py).  Exact: the padded tail is invisible
+        # to attention (klen), the convolutions only look left (the look-ahead conv sees zeros, as in the reference).
+        lb = int(getattr(self, "length_bucket", 0) or 0)
+        N = -(-Nv // lb) * lb if lb > 0 else Nv
+        padded = lb > 0                    # with bucketing on, an exact fit also takes the masked path: one graph per bucket
         T = 2 * N
         D = embeddings.shape[1]
         bf = self._buffers(B, N, D)
@@ -526,19 +547,25 @@ class CausalMaskedDiffWithXvec:
                  ldo32=cfg.output_size)
         # tokens -> embedding -> encoder -> encoder_proj = mu (flow.py:290-302)
         bf["idx"][:, :Np].copy_(prompt_tokens.to(dev, torch.int32))
-        bf["idx"][:, Np:].copy_(tokens.to(dev, torch.int32))
+        bf["idx"][:, Np:Nv].copy_(tokens.to(dev, torch.int32))
+        klen_enc = klen_est = None
+        if padded:
+            bf["idx"][:, Nv:].fill_(-1)
+            klen_enc, klen_est = bf["klen_enc"], bf["klen_est"]
+            klen_enc.fill_(Nv)
+            klen_est.fill_(2 * Nv)
         ews = self.encoder._workspace(B, N)
         ops.embedding(self.emb_table, bf["idx"].view(-1), ews["tok"].view(B * N, cfg.enc_dim))
-        self.encoder.forward_tokens(ews["tok"], B, N)
+        self.encoder.forward_tokens(ews["tok"], B, N, klen=klen_enc, n_valid=Nv if padded else None)
         ops.linear(ews["b"]["xa"].view(B * T, cfg.enc_dim), self.proj_w, bias=self.proj_b, out_f32=ews["mu"].view(B * T, cfg.output_size))
         # conditions: prompt mel then zeros (flow.py:305-307)
         Tp = prompt_feats.shape[1]
         bf["cond"].zero_()
         bf["cond"][:, :Tp].copy_(prompt_feats.to(dev, torch.float32))
         bf["x"].copy_(self.decoder._noise_cl[:T].unsqueeze(0).expand(B, -1, -1))
-        self.decoder.solve(bf["x"], ews["mu"], bf["spks"], bf["cond"], n_timesteps)
+        self.decoder.solve(bf["x"], ews["mu"], bf["spks"], bf["cond"], n_timesteps, klen=klen_est)
         ops.to_channels_first(bf["x"], bf["mel"])
-        return bf["mel"][:, :, Tp:]
+        return bf["mel"][:, :, Tp:2 * Nv]
 
     @torch.no_grad()
     def inference(self, token, token_len, prompt_token, prompt_token_len, prompt_feat, prompt_feat_len, embedding,

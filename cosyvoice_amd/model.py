@@ -50,6 +50,9 @@ class CosyVoice2Model:
         # high-priority side stream: the decode loop is a chain of short dependent kernels that must not queue behind the
         # flow GEMMs of the previous batch when both streams are busy (tts_batches)
         self.llm_context = torch.cuda.stream(torch.cuda.Stream(self.device, priority=-1))
+        # streaming requests run the flow at the next multiple of this many tokens (tail masked, exact): requests of arbitrary
+        # prompt / chunk lengths then share a handful of captured estimator graphs instead of capturing one per length
+        self.stream_length_bucket = 25
         self.llm_cu_slots = 8   # tts_batches: CU slots per XCD (of 32) owned by the decode loops; 0 = no partition
         self.llm_loops = 2      # tts_batches: concurrent decode loops (each its own batch / KV caches) on those CUs
         self.lock = threading.Lock()
@@ -137,6 +140,7 @@ class CosyVoice2Model:
         p = threading.Thread(target=self.llm_job, args=(text, prompt_text, llm_prompt_speech_token, llm_embedding, this_uuid))
         p.start()
         if stream is True:
+            self.flow.length_bucket = self.stream_length_bucket
             token_offset = 0
             need = self.token_hop_len + self.flow.pre_lookahead_len
             while True:

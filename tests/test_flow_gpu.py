@@ -125,3 +125,31 @@ def test_inference_without_prompt_and_minimal_length():
         assert cache is None and mel.shape == (1, 80, 2 * n_g) and mel.dtype == torch.float32
         a, b = _report(f"mel[N_p={n_p},N_g={n_g}]", mel, ref)
         assert a < 2e-2 and b < 5e-3
+
+
+def test_length_bucketing_is_exact():
+    """length_bucket pads a request to the next multiple of 25 tokens with the tail masked (attention klen, zeroed look-ahead
+    input): same mel as the unpadded run, and requests of different lengths inside one bucket share ONE captured graph."""
+    from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
+    cfg = FlowConfig.tiny()
+    sd = flow_state_dict(cfg)
+    ref_flow = CausalMaskedDiffWithXvec(cfg, dtype=torch.float16).load_state_dict(sd)
+    flow = CausalMaskedDiffWithXvec(cfg, dtype=torch.float16).load_state_dict(sd)
+    flow.length_bucket = 25
+    flow.decoder.use_graph = True
+    g = torch.Generator().manual_seed(13)
+    emb = torch.randn(1, cfg.spk_embed_dim, generator=g)
+    n_p = 10
+    ptok = torch.randint(0, cfg.vocab_size, (1, n_p), generator=g, dtype=torch.int32)
+    pfeat = torch.clamp(torch.randn(1, 2 * n_p, 80, generator=g) * 2 - 6, -11.5, 2.0)
+    for chunk in (0, 25):
+        ref_flow.encoder.static_chunk_size = flow.encoder.static_chunk_size = chunk
+        for n_g in (29, 33, 40, 15):                     # 39, 43, 50 tokens -> one 50-token bucket; 25 -> exact fit
+            tok = torch.randint(0, cfg.vocab_size, (1, n_g), generator=g, dtype=torch.int32)
+            want = ref_flow.inference_batch(tok, ptok, pfeat, emb).clone()
+            got = flow.inference_batch(tok, ptok, pfeat, emb).clone()      # first call of a bucket captures, later ones replay
+            got2 = flow.inference_batch(tok, ptok, pfeat, emb).clone()
+            assert got.shape == want.shape == (1, 80, 2 * n_g)
+            assert (got - want).abs().max().item() < 2e-4, (chunk, n_g, (got - want).abs().max().item())
+            assert (got2 - want).abs().max().item() < 2e-4
+    assert len(flow.decoder._graphs) == 2, len(flow.decoder._graphs)      # buckets of 25 and 50 tokens

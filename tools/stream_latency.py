@@ -15,8 +15,12 @@ llm = Qwen2LM(lc, dtype=torch.bfloat16, max_batch=1, ctx_max=1024, max_out=600)
 flow = CausalMaskedDiffWithXvec(fc, dtype=torch.float16); hift = HiFTGenerator(hc, dtype=torch.float32)
 model = CosyVoice2Model(llm, flow, hift).load_state_dicts(llm_state_dict(lc), flow_state_dict(fc), hift_state_dict(hc))
 flow.decoder.use_graph = True
-texts, forced, ptext, pspeech, pfeat, emb = B.make_inputs(lc, fc, 100)
-for rep in range(3):
+texts, forced, ptext, pspeech0, pfeat0, emb = B.make_inputs(lc, fc, 100)
+bucket = int(sys.argv[1]) if len(sys.argv) > 1 else 25
+model.stream_length_bucket = bucket
+print(f"stream_length_bucket = {bucket}")
+for rep, cut in enumerate((0, 0, 7, 13, 7)):          # prompt shortened by `cut` tokens: a request of a new length
+    pspeech, pfeat = pspeech0[:, :250 - cut], pfeat0[:, :2 * (250 - cut)]
     t0 = time.perf_counter()
     stamps, samples = [], []
     for out in model.tts(text=texts[0], flow_embedding=emb, llm_embedding=torch.zeros(0, 192), prompt_text=ptext,
@@ -25,5 +29,5 @@ for rep in range(3):
         samples.append(out["tts_speech"].shape[1])
     audio = sum(samples) / 24000
     gaps = [b - a for a, b in zip(stamps, stamps[1:])]
-    print(f"run {rep}: first chunk after {1e3*stamps[0]:.0f} ms ({samples[0]/24000:.2f} s of audio), {len(stamps)} chunks, "
+    print(f"run {rep} (prompt {pspeech.shape[1]} tokens): first chunk after {1e3*stamps[0]:.0f} ms ({samples[0]/24000:.2f} s of audio), {len(stamps)} chunks, "
           f"mean gap {1e3*sum(gaps)/max(len(gaps),1):.0f} ms, total {1e3*stamps[-1]:.0f} ms for {audio:.1f} s of audio (RTF {stamps[-1]/audio:.3f})", flush=True)
