@@ -180,11 +180,14 @@ class UpsampleConformerEncoder:
         ws = self._workspace(R, N)
         wa, wb = ws["a"], ws["b"]
         self._embed(self.embed, tok_emb_act.view(R * N, D), wa, R)
-        if n_valid is not None and n_valid < N:
-            # length-bucketed call: positions beyond the real sequence must read as the zero padding the look-ahead conv of the
-            # reference sees beyond the end (upsample_encoder.py:81-88); everything after it only looks left or is masked by klen
-            wa["xs"][:, n_valid:].zero_()
-            wa["xa"][:, n_valid:].zero_()
+        if n_valid is not None:
+            # padded call (length bucket / ragged batch): positions beyond a sequence's real end must read as the zero padding the
+            # look-ahead conv of the reference sees there (upsample_encoder.py:81-88); everything after it only looks left or is
+            # masked by klen
+            for r, nv in enumerate(n_valid if isinstance(n_valid, (list, tuple)) else [n_valid] * R):
+                if nv < N:
+                    wa["xs"][r, nv:].zero_()
+                    wa["xa"][r, nv:].zero_()
         # PreLookaheadLayer (upsample_encoder.py:81-96): conv k4 looking right (zero beyond the end), leaky 0.01,
         # conv k3 looking left, residual
         ops.conv1d_cl(wa["xa"], self.pl1_w, cfg.pre_lookahead_len + 1, pad_left=0, bias=self.pl1_b, act=ops.ACT_LEAKY,
@@ -566,6 +569,44 @@ class CausalMaskedDiffWithXvec:
         self.decoder.solve(bf["x"], ews["mu"], bf["spks"], bf["cond"], n_timesteps, klen=klen_est)
         ops.to_channels_first(bf["x"], bf["mel"])
         return bf["mel"][:, :, Tp:2 * Nv]
+
+    @torch.no_grad()
+    def inference_ragged(self, tokens, prompt_tokens, prompt_feats, embeddings: torch.Tensor, n_timesteps: int = 10):
+        """B utterances of DIFFERENT lengths in one batched pass: lists of tokens (Ng_b,), prompt_tokens (Np_b,), prompt_feats
+        (2*Np_b, 80); embeddings (B, D).  Returns a list of mels (80, 2*Ng_b) fp32, each identical to its batch-1 result: rows
+        are padded to the longest (rounded up to ``length_bucket``) and the tails masked exactly as in a length-bucketed call."""
+        assert self._loaded
+        cfg, dev = self.cfg, self.device
+        B = len(tokens)
+        nps = [int(t.numel()) for t in prompt_tokens]
+        nvs = [nps[b] + int(tokens[b].numel()) for b in range(B)]
+        lb = int(getattr(self, "length_bucket", 0) or 0) or 1
+        N = -(-max(nvs) // lb) * lb
+        T = 2 * N
+        D = embeddings.shape[1]
+        bf = self._buffers(B, N, D)
+        bf["emb_in"].copy_(embeddings.to(dev, torch.float32))
+        ops.layernorm(bf["emb_in"], None, None, 1e-24 / D, rms=True, out_scale=1.0 / math.sqrt(D), out_act=bf["emb_n"][:, :D])
+        ops.gemm(bf["emb_n"], self.spk_w, B, cfg.output_size, D, lda=bf["emb_n"].stride(0), bias=self.spk_b, out_f32=bf["spks"],
+                 ldo32=cfg.output_size)
+        bf["idx"].fill_(-1)
+        bf["cond"].zero_()
+        for b in range(B):
+            bf["idx"][b, :nps[b]].copy_(prompt_tokens[b].reshape(-1).to(dev, torch.int32))
+            bf["idx"][b, nps[b]:nvs[b]].copy_(tokens[b].reshape(-1).to(dev, torch.int32))
+            assert prompt_feats[b].shape[-2] == 2 * nps[b]
+            bf["cond"][b, :2 * nps[b]].copy_(prompt_feats[b].reshape(-1, cfg.output_size).to(dev, torch.float32))
+        klen_enc, klen_est = bf["klen_enc"], bf["klen_est"]
+        klen_enc.copy_(torch.tensor(nvs, dtype=torch.int32))
+        klen_est.copy_(torch.tensor([2 * n for n in nvs], dtype=torch.int32))
+        ews = self.encoder._workspace(B, N)
+        ops.embedding(self.emb_table, bf["idx"].view(-1), ews["tok"].view(B * N, cfg.enc_dim))
+        self.encoder.forward_tokens(ews["tok"], B, N, klen=klen_enc, n_valid=nvs)
+        ops.linear(ews["b"]["xa"].view(B * T, cfg.enc_dim), self.proj_w, bias=self.proj_b, out_f32=ews["mu"].view(B * T, cfg.output_size))
+        bf["x"].copy_(self.decoder._noise_cl[:T].unsqueeze(0).expand(B, -1, -1))
+        self.decoder.solve(bf["x"], ews["mu"], bf["spks"], bf["cond"], n_timesteps, klen=klen_est)
+        ops.to_channels_first(bf["x"], bf["mel"])
+        return [bf["mel"][b, :, 2 * nps[b]:2 * nvs[b]].clone() for b in range(B)]
 
     @torch.no_grad()
     def inference(self, token, token_len, prompt_token, prompt_token_len, prompt_feat, prompt_feat_len, embedding,

@@ -232,7 +232,7 @@ class CosyVoice2Model:
     def _flow_hift(self, b, toks):
         """Flow + HiFT of one batch.  Equal generated lengths (teacher-forced runs, the benchmark): one batched pass ->
         wav (B, S).  Free-running sampling ends every sequence at its own step: flow + HiFT then run per utterance (the
-        batched flow path assumes one common length) -> list of B waveforms (S_b,)."""
+        flow runs once over the ragged batch, HiFT per utterance) -> list of B waveforms (S_b,)."""
         n = len(toks[0])
         zero = torch.zeros(1, 1, 0)
         if all(len(t) == n for t in toks):
@@ -240,12 +240,15 @@ class CosyVoice2Model:
             mel = self.flow.inference_batch(tok, b["flow_prompt_speech_tokens"], b["prompt_speech_feats"], b["flow_embeddings"])
             wav, _ = self.hift.inference(speech_feat=mel.contiguous(), cache_source=zero)
             return wav
+        # one batched flow pass over the ragged batch (rows padded to the longest, tails masked: exact), HiFT per utterance
+        # (its symmetric convolutions would see the padding)
+        B = len(toks)
+        mels = self.flow.inference_ragged([torch.tensor(t, dtype=torch.int32) for t in toks],
+                                          [b["flow_prompt_speech_tokens"][i] for i in range(B)],
+                                          [b["prompt_speech_feats"][i] for i in range(B)], b["flow_embeddings"])
         outs = []
-        for i, t in enumerate(toks):
-            tok = torch.tensor([t], dtype=torch.int32, device=self.device)
-            mel = self.flow.inference_batch(tok, b["flow_prompt_speech_tokens"][i:i + 1], b["prompt_speech_feats"][i:i + 1],
-                                            b["flow_embeddings"][i:i + 1])
-            wav, _ = self.hift.inference(speech_feat=mel.contiguous(), cache_source=zero)
+        for mel in mels:
+            wav, _ = self.hift.inference(speech_feat=mel.unsqueeze(0).contiguous(), cache_source=zero)
             outs.append(wav[0].clone())
         return outs
 

@@ -153,3 +153,24 @@ def test_length_bucketing_is_exact():
             assert (got - want).abs().max().item() < 2e-4, (chunk, n_g, (got - want).abs().max().item())
             assert (got2 - want).abs().max().item() < 2e-4
     assert len(flow.decoder._graphs) == 2, len(flow.decoder._graphs)      # buckets of 25 and 50 tokens
+
+
+def test_ragged_batch_equals_single_utterances():
+    """inference_ragged: utterances of different prompt and token lengths in ONE batched pass (rows padded, tails masked) give
+    the mel each utterance gives alone."""
+    from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
+    cfg = FlowConfig.tiny()
+    flow = CausalMaskedDiffWithXvec(cfg, dtype=torch.float16).load_state_dict(flow_state_dict(cfg))
+    g = torch.Generator().manual_seed(23)
+    shapes = [(10, 29), (0, 7), (4, 41), (13, 1)]          # (prompt tokens, generated tokens)
+    toks = [torch.randint(0, cfg.vocab_size, (n,), generator=g, dtype=torch.int32) for _, n in shapes]
+    ptoks = [torch.randint(0, cfg.vocab_size, (p,), generator=g, dtype=torch.int32) for p, _ in shapes]
+    pfeats = [torch.clamp(torch.randn(2 * p, 80, generator=g) * 2 - 6, -11.5, 2.0) for p, _ in shapes]
+    embs = torch.randn(len(shapes), cfg.spk_embed_dim, generator=g)
+    for chunk in (0, 25):
+        flow.encoder.static_chunk_size = chunk
+        alone = [flow.inference_batch(toks[b][None], ptoks[b][None], pfeats[b][None], embs[b:b + 1])[0].clone() for b in range(len(shapes))]
+        together = flow.inference_ragged(toks, ptoks, pfeats, embs)
+        for b, (p, n) in enumerate(shapes):
+            assert together[b].shape == alone[b].shape == (80, 2 * n)
+            assert (together[b] - alone[b]).abs().max().item() < 2e-4, (chunk, b, (together[b] - alone[b]).abs().max().item())
