@@ -231,3 +231,36 @@ class PhonemeFrontConfig:
         return PhonemeFrontConfig(text_token_size=30, text_token_dim=24, text_tone_size=5, text_tone_dim=8, text_lang_size=2,
                                   text_lang_dim=8, text_prsd_size=4, text_prsd_dim=8, enc_dim=128, enc_heads=2,
                                   enc_linear_units=256, enc_blocks=2, spk_embed_dim=16)   # src_heads / src_linear_units are hard-coded in the reference
+
+
+@dataclass(frozen=True)
+class TransformerLMConfig:
+    # CosyVoice-v1 TransformerLM (/root/reference/cosyvoice/llm/llm.py:41-237) as configured by
+    # examples/tts_vc/cosyvoice/conf/cosyvoice.yaml:17-66
+    text_token_size: int = 60515
+    text_encoder_input_size: int = 512
+    enc_dim: int = 1024            # text_encoder: ConformerEncoder (rel-pos, no cnn, no macaron, static_chunk_size 1 = causal)
+    enc_heads: int = 16
+    enc_linear_units: int = 4096
+    enc_blocks: int = 6
+    llm_dim: int = 1024            # llm: TransformerEncoder ('linear_legacy' input layer, rel-pos attention, ReLU FFN)
+    llm_heads: int = 16
+    llm_linear_units: int = 4096
+    llm_blocks: int = 14
+    speech_token_size: int = 4096
+    spk_embed_dim: int = 192
+    top_p: float = 0.8             # non_random_ras_sampling (yaml :57-62)
+    top_k: int = 10
+    win_size: int = 50
+    tau_r: float = 0.1
+    expand_scale: int = 2
+
+    @staticmethod
+    def full() -> "TransformerLMConfig":
+        return TransformerLMConfig()
+
+    @staticmethod
+    def tiny() -> "TransformerLMConfig":
+        return TransformerLMConfig(text_token_size=200, text_encoder_input_size=32, enc_dim=128, enc_heads=2, enc_linear_units=256,
+                                   enc_blocks=2, llm_dim=128, llm_heads=2, llm_linear_units=256, llm_blocks=3, speech_token_size=96,
+                                   spk_embed_dim=16)

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const cv_norm_params p) {
     for (int r = 0; r < 4; ++r) {
       float y = (o[r] - mean) * rstd * gg[r] + bb[r];
       if (p.act == CV_ACT_MISH) y = act_mish(y);
+      else if (p.act == CV_ACT_LEAKY) y = fmaxf(y, 0.f);   // ReLU (the params carry no slope): LegacyLinearNoSubsampling
       y += aa[r];
       o[r] = y * p.out_scale;
     }

@@ -54,8 +54,9 @@ class UpsampleConformerEncoder:
     def output_size(self):
         return self.cfg.enc_dim
 
-    def _load_layer(self, P, sd, name):
-        """One ConformerEncoderLayer (rel-pos self-attention + FFN, no cnn module, no macaron): packed operands."""
+    def _load_layer(self, P, sd, name, norm_mha="norm_mha", norm_ff="norm_ff"):
+        """One ConformerEncoderLayer (rel-pos self-attention + FFN, no cnn module, no macaron): packed operands.  The
+        TransformerEncoderLayer of the v1 LM has the same tensors under the names norm1 / norm2."""
         a = f"{name}.self_attn."
         bq = sd[a + "linear_q.bias"].float()
         wq = sd[a + "linear_q.weight"].float()
@@ -71,8 +72,8 @@ class UpsampleConformerEncoder:
                     bout=bout.to(device=self.device).contiguous(),
                     w1=P.w(f"{name}.feed_forward.w_1.weight"), b1=P.f32(f"{name}.feed_forward.w_1.bias"),
                     w2=P.w(f"{name}.feed_forward.w_2.weight"), b2=P.f32(f"{name}.feed_forward.w_2.bias"),
-                    g_mha=P.f32(f"{name}.norm_mha.weight"), b_mha=P.f32(f"{name}.norm_mha.bias"),
-                    g_ff=P.f32(f"{name}.norm_ff.weight"), b_ff=P.f32(f"{name}.norm_ff.bias"))
+                    g_mha=P.f32(f"{name}.{norm_mha}.weight"), b_mha=P.f32(f"{name}.{norm_mha}.bias"),
+                    g_ff=P.f32(f"{name}.{norm_ff}.weight"), b_ff=P.f32(f"{name}.{norm_ff}.bias"))
 
     @staticmethod
     def _load_embed(P, name):
@@ -143,7 +144,7 @@ class UpsampleConformerEncoder:
         self._ws[key] = ws
         return ws
 
-    def _layer(self, l, w, R, p_l, chunk, klen, last_act=None):
+    def _layer(self, l, w, R, p_l, chunk, klen, last_act=None, act=None, causal=False):
         cfg = self.cfg
         D, H, U = cfg.enc_dim, cfg.enc_heads, cfg.enc_linear_units
         T, Tp, ldb = w["T"], w["Tp"], w["ldb"]
@@ -158,11 +159,12 @@ class UpsampleConformerEncoder:
         ops.gemm(w["q"][:, :, D:], p_l, T, 2 * T - 1, 64, batch=R * H, batch_inner=H, a_bs=(64, T * 3 * D), lda=3 * D,
                  w_bs=(64, 0), ldw=D, out_scale=scale, out_f32=w["bd"], o32_bs=(T * ldb, H * T * ldb), ldo32=ldb)
         ops.attention(w["q"], w["q"][:, :, 2 * D:], w["vt"], w["ao"], B=R, H=H, Hkv=H, Tq=T, Tk=T, scale=scale, q_bs=T * 3 * D,
-                      ldq=3 * D, k_bs=T * 3 * D, ldk=3 * D, vt_ld=Tp, o_bs=T * D, ldo=D, klen=klen, chunk=chunk,
+                      ldq=3 * D, k_bs=T * 3 * D, ldk=3 * D, vt_ld=Tp, o_bs=T * D, ldo=D, klen=klen, chunk=chunk, causal=causal,
                       bias=w["bd"].view(-1)[T - 1:], bias_bs=H * T * ldb, bias_hs=T * ldb, bias_ld=ldb - 1)
         ops.linear(w["ao"].view(R * T, D), l["wout"], bias=l["bout"], res=xs2, out_f32=xs2)
         ops.layernorm(xs2, l["g_ff"], l["b_ff"], 1e-12, out_act=w["xn"].view(R * T, D))
-        ops.linear(w["xn"].view(R * T, D), l["w1"], bias=l["b1"], act=ops.ACT_SILU, out_act=w["ff"].view(R * T, U))
+        ffn_act = dict(act=ops.ACT_SILU) if act is None else act      # conformer FFN: swish; v1 TransformerEncoderLayer: ReLU
+        ops.linear(w["xn"].view(R * T, D), l["w1"], bias=l["b1"], out_act=w["ff"].view(R * T, U), **ffn_act)
         ops.linear(w["ff"].view(R * T, U), l["w2"], bias=l["b2"], res=xs2, out_f32=xs2,
                    out_act=(last_act.view(R * T, D) if last_act is not None else None))
 

@@ -366,3 +366,44 @@ def phoneme_lm_state_dict(pcfg, lcfg: LlmConfig, seed: int = 1986, round_to=None
     if lcfg.tie_word_embeddings:
         sd["llm.model.lm_head.weight"] = sd["llm.model.model.embed_tokens.weight"]
     return sd
+
+
+# --------------------------------------------------------------------------- CosyVoice-v1 TransformerLM
+def _transformer_layer(specs, name, dim, heads, units):
+    """TransformerEncoderLayer with rel-pos attention (encoder_layer.py:24-107): same tensors as a conformer layer, norm1 / norm2."""
+    dk = dim // heads
+    for n in ("linear_q", "linear_k", "linear_v", "linear_out"):
+        _linear(specs, f"{name}.self_attn.{n}", dim, dim)
+    _linear(specs, f"{name}.self_attn.linear_pos", dim, dim, bias=False)
+    bound = math.sqrt(6.0 / (heads + dk))
+    specs.append((f"{name}.self_attn.pos_bias_u", (heads, dk), "uniform", bound))
+    specs.append((f"{name}.self_attn.pos_bias_v", (heads, dk), "uniform", bound))
+    _linear(specs, f"{name}.feed_forward.w_1", units, dim)
+    _linear(specs, f"{name}.feed_forward.w_2", dim, units)
+    _ln(specs, f"{name}.norm1", dim)
+    _ln(specs, f"{name}.norm2", dim)
+
+
+def transformer_lm_specs(cfg) -> List[Spec]:
+    s: List[Spec] = []
+    s.append(("text_embedding.weight", (cfg.text_token_size, cfg.text_encoder_input_size), "normal", 1.0))
+    _linear(s, "text_encoder.embed.out.0", cfg.enc_dim, cfg.text_encoder_input_size)
+    _ln(s, "text_encoder.embed.out.1", cfg.enc_dim)
+    _ln(s, "text_encoder.after_norm", cfg.enc_dim)
+    for i in range(cfg.enc_blocks):
+        _conformer_layer(s, f"text_encoder.encoders.{i}", cfg.enc_dim, cfg.enc_heads, cfg.enc_linear_units)
+    _linear(s, "text_encoder_affine_layer", cfg.llm_dim, cfg.enc_dim)
+    s.append(("llm_embedding.weight", (2, cfg.llm_dim), "normal", 1.0))
+    _linear(s, "llm.embed.out.0", cfg.llm_dim, cfg.llm_dim)
+    _ln(s, "llm.embed.out.1", cfg.llm_dim)
+    _ln(s, "llm.after_norm", cfg.llm_dim)
+    for i in range(cfg.llm_blocks):
+        _transformer_layer(s, f"llm.encoders.{i}", cfg.llm_dim, cfg.llm_heads, cfg.llm_linear_units)
+    _linear(s, "llm_decoder", cfg.speech_token_size + 1, cfg.llm_dim, gain=2.0, bias_std=0.1)
+    s.append(("speech_embedding.weight", (cfg.speech_token_size, cfg.llm_dim), "normal", 1.0))
+    _linear(s, "spk_embed_affine_layer", cfg.llm_dim, cfg.spk_embed_dim)
+    return s
+
+
+def transformer_lm_state_dict(cfg, seed: int = 1986, round_to=None):
+    return materialize(transformer_lm_specs(cfg), seed, round_to)

@@ -507,11 +507,61 @@ def golden_v1_orchestrator():
          stream_chunk_samples=out["stream"], full_samples=out["full"])
 
 
+def golden_llm_v1():
+    """CosyVoice-v1 TransformerLM (llm/llm.py:41-237): the reference module itself (reference ConformerEncoder text encoder,
+    reference TransformerEncoder with its forward_chunk attention cache) on key-seeded weights; sampling_ids is replaced by a
+    recorder that stores the log-probabilities of every step and returns teacher-forced ids."""
+    from cosyvoice_amd.config import TransformerLMConfig
+    from cosyvoice_amd.weights import transformer_lm_state_dict
+    from cosyvoice.llm.llm import TransformerLM
+    from cosyvoice.transformer.encoder import ConformerEncoder, TransformerEncoder
+    from cosyvoice.utils.common import non_random_ras_sampling
+    c = TransformerLMConfig.tiny()
+    sd = transformer_lm_state_dict(c, seed=41)
+    enc = ConformerEncoder(input_size=c.text_encoder_input_size, output_size=c.enc_dim, attention_heads=c.enc_heads,
+                           linear_units=c.enc_linear_units, num_blocks=c.enc_blocks, dropout_rate=0.1, positional_dropout_rate=0.1,
+                           attention_dropout_rate=0.0, normalize_before=True, input_layer="linear", pos_enc_layer_type="rel_pos_espnet",
+                           selfattention_layer_type="rel_selfattn", use_cnn_module=False, macaron_style=False, use_dynamic_chunk=False,
+                           use_dynamic_left_chunk=False, static_chunk_size=1)
+    llm = TransformerEncoder(input_size=c.llm_dim, output_size=c.llm_dim, attention_heads=c.llm_heads, linear_units=c.llm_linear_units,
+                             num_blocks=c.llm_blocks, dropout_rate=0.1, positional_dropout_rate=0.1, attention_dropout_rate=0.0,
+                             input_layer="linear_legacy", pos_enc_layer_type="rel_pos_espnet", selfattention_layer_type="rel_selfattn",
+                             static_chunk_size=1)
+    m = TransformerLM(text_encoder_input_size=c.text_encoder_input_size, llm_input_size=c.llm_dim, llm_output_size=c.llm_dim,
+                      text_token_size=c.text_token_size, speech_token_size=c.speech_token_size, text_encoder=enc, llm=llm,
+                      sampling=non_random_ras_sampling, spk_embed_dim=c.spk_embed_dim)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and not [k for k in missing if "pe" not in k.split(".")[-1]], (missing, unexpected)
+    m.eval()
+    m.fp16 = False
+    g = torch.Generator().manual_seed(29)
+    L, Lp, N = 7, 3, 9
+    text = torch.randint(0, c.text_token_size, (1, L), generator=g)
+    ptext = torch.randint(0, c.text_token_size, (1, Lp), generator=g)
+    pspeech = torch.randint(0, c.speech_token_size, (1, N), generator=g)
+    emb = torch.randn(1, c.spk_embed_dim, generator=g)
+    forced = torch.randint(0, c.speech_token_size, (12,), generator=g).tolist()
+    rows = []
+
+    def recorder(weighted_scores, decoded_tokens, sampling, ignore_eos=True):
+        rows.append(weighted_scores.detach().clone())
+        i = len(decoded_tokens)
+        return torch.tensor(forced[i] if i < len(forced) else c.speech_token_size)
+
+    m.sampling_ids = recorder
+    with torch.inference_mode():
+        toks = list(m.inference(text=text, text_len=torch.tensor([L]), prompt_text=ptext, prompt_text_len=torch.tensor([Lp]),
+                                prompt_speech_token=pspeech, prompt_speech_token_len=torch.tensor([N]), embedding=emb))
+    assert toks == forced and len(rows) == len(forced) + 1
+    save("llm_v1_tiny", text=text.to(torch.int32), prompt_text=ptext.to(torch.int32), prompt_speech_token=pspeech.to(torch.int32),
+         embedding=emb, forced=np.array(forced, dtype=np.int32), logp=torch.stack(rows), seed=np.array(41))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     install_stubs()
-    which = sys.argv[1:] or ["hift", "flow", "llm", "bigvgan", "frontend", "phoneme", "v1orch"]
+    which = sys.argv[1:] or ["hift", "flow", "llm", "bigvgan", "frontend", "phoneme", "v1orch", "llmv1"]
     if "hift" in which:
         golden_hift()
     if "flow" in which:
@@ -527,6 +577,8 @@ def main():
         golden_llm_phoneme()
     if "v1orch" in which:
         golden_v1_orchestrator()
+    if "llmv1" in which:
+        golden_llm_v1()
 
 
 if __name__ == "__main__":

@@ -167,3 +167,18 @@ def test_phoneme_lm_front_end_vs_reference(golden_dir):
     x = op.phoneme_lm_input(sd, pc, lc, g["text"], g["pho"], g["prompt_text"], g["prompt_pho"], g["prompt_speech_token"], g["embedding"])
     assert x.shape == g["lm_input"].shape
     assert (x - g["lm_input"]).abs().max().item() < 1e-5
+
+
+def test_v1_transformer_lm_vs_reference(golden_dir):
+    """oracle.llm_v1 (full causal pass) against the log-probabilities of the reference's own TransformerLM.inference, which
+    decodes step by step through forward_chunk with an attention cache."""
+    from cosyvoice_amd.config import TransformerLMConfig
+    from cosyvoice_amd.weights import transformer_lm_state_dict
+    from oracle import llm_v1 as o1
+    g = _load(golden_dir, "llm_v1_tiny")
+    c = TransformerLMConfig.tiny()
+    sd = transformer_lm_state_dict(c, seed=int(g["seed"]))
+    lp = o1.forced_logp(sd, c, g["text"], g["prompt_text"], g["prompt_speech_token"], g["embedding"], g["forced"].tolist())
+    fin = torch.isfinite(g["logp"])
+    assert lp.shape == g["logp"].shape and (torch.isinf(lp) == ~fin).all()
+    assert (lp[fin] - g["logp"][fin]).abs().max().item() < 1e-4
