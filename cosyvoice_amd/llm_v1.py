@@ -200,7 +200,7 @@ class TransformerLM:
         sent = 0
         for i in range(max_len):
             self._logits_of_last(T)
-            if collect_logp is not None:   # the reference masks EOS on the log-softmax output, without renormalising (:226-227)
+            if collect_logp is not None:   # the reference masks EOS on the log-softmax output, without renormalising (:227-229)
                 lp = st["logits"][0, :c.speech_token_size + 1].log_softmax(-1).cpu()
                 if i == 0:
                     lp[c.speech_token_size] = -float("inf")

@@ -59,7 +59,7 @@ def llm_hidden(sd, cfg, seq):
 
 def forced_logp(sd, cfg, text, prompt_text, prompt_speech_token, embedding, forced):
     """log-softmax rows the decode loop sees when the emitted ids are forced: row i = step i (llm.py:221-236; the EOS column of
-    row 0 is -inf, :226-227)."""
+    row 0 is -inf, :227-229)."""
     seq = lm_input(sd, cfg, text, prompt_text, prompt_speech_token, embedding)
     L0 = seq.shape[1]
     if len(forced):

@@ -22,7 +22,7 @@ def test_forced_logp_vs_reference_golden(golden_dir, dt, tol):
     ref = g["logp"]
     assert lp.shape == ref.shape
     fin = torch.isfinite(ref)
-    assert (~fin).sum() == 1 and torch.isinf(lp[0, c.speech_token_size])        # EOS masked at the first step (llm.py:226-227)
+    assert (~fin).sum() == 1 and torch.isinf(lp[0, c.speech_token_size])        # EOS masked at the first step (llm.py:227-229)
     err = (lp[fin] - ref[fin]).abs().max().item()
     agree = (lp[:, :c.speech_token_size].argmax(-1) == ref[:, :c.speech_token_size].argmax(-1)).float().mean().item()
     print(f"v1 llm logp[{dt}] Linf {err:.3e}, argmax agreement {agree:.2f}")
