@@ -51,6 +51,19 @@ class NormParams(C.Structure):
     ]
 
 
+class GroupNormParams(C.Structure):
+    _fields_ = [
+        ("B", _i32), ("T", _i32), ("C", _i32), ("groups", _i32), ("eps", _f32),
+        ("x", _vp), ("x_bs", _i64), ("ldx", _i32),
+        ("gamma", _vp), ("beta", _vp),
+        ("add", _vp), ("add_ld", _i32),
+        ("act", _i32), ("out_dtype", _i32),
+        ("out_f32", _vp), ("o32_bs", _i64), ("ldo32", _i32),
+        ("out_act", _vp), ("oa_bs", _i64), ("ldoa", _i32),
+        ("partial", _vp),
+    ]
+
+
 class AttnParams(C.Structure):
     _fields_ = [
         ("dtype", _i32), ("B", _i32), ("H", _i32), ("Hkv", _i32), ("Tq", _i32), ("Tk", _i32),
@@ -125,7 +138,8 @@ EXPORTS = ["cv_version", "cv_arch", "cv_gemm", "cv_layernorm", "cv_attention",
            "cv_graph_destroy", "cv_graph_launch_direct", "cv_graph_num_launches", "cv_stream_create_cumask",
            "cv_stream_destroy", "cv_skinny_gemm", "cv_pack_skinny", "cv_rmsnorm_reduce", "cv_rope_append",
            "cv_decode_attention", "cv_sample_ras", "cv_sizeof_skinny_params", "cv_sizeof_sample_params", "cv_anti_alias_act", "cv_anti_alias_act_cl",
-           "cv_stft_magnitude", "cv_log_clamp_channels_first"]
+           "cv_stft_magnitude", "cv_log_clamp_channels_first", "cv_groupnorm_cl", "cv_groupnorm_workspace_floats",
+           "cv_interp_linear_cl"]
 
 TORCH_DT = {torch.float32: CV_F32, torch.bfloat16: CV_BF16, torch.float16: CV_F16}
 DT_TORCH = {v: k for k, v in TORCH_DT.items()}

@@ -109,6 +109,27 @@ class FlowConfig:
 
 
 @dataclass(frozen=True)
+class FlowV1Config(FlowConfig):
+    """CosyVoice-v1 MaskedDiffWithXvec (/root/reference/cosyvoice/flow/flow.py:25-62, examples/tts_vc/cosyvoice/conf/
+    cosyvoice.yaml:66-114): plain ConformerEncoder, InterpolateRegulator, non-causal two-level ConditionalDecoder
+    channels=[256, 256] (stride-2 Downsample1D / ConvTranspose Upsample1D, GroupNorm(8) blocks)."""
+    vocab_size: int = 4096
+    input_frame_rate: int = 50
+    reg_layers: int = 4           # len(sampling_ratios)
+    reg_groups: int = 1           # InterpolateRegulator(groups=1), length_regulator.py:22-28
+    est_groups: int = 8           # Block1D(groups=8), flow/components/decoder.py:31
+    hop_size: int = 256           # mel hop hard-coded in flow.py:143 / length_regulator.py:55
+
+    @staticmethod
+    def full() -> "FlowV1Config":
+        return FlowV1Config()
+
+    @staticmethod
+    def tiny() -> "FlowV1Config":
+        return FlowV1Config(vocab_size=200, enc_linear_units=128, enc_blocks=1, est_n_blocks=1, est_mid_blocks=2)
+
+
+@dataclass(frozen=True)
 class LlmConfig:
     # Qwen2LM, /root/reference/cosyvoice/llm/llm.py:769-804; backbone shape = Qwen2.5-0.5B config.json
     hidden_size: int = 896

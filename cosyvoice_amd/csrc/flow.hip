@@ -70,6 +70,22 @@ __global__ __launch_bounds__(256) void cfm_update_kernel(float* x, const float* 
   }
 }
 
+// F.interpolate(mode='linear', align_corners=False) along T of a channels-last fp32 tensor (InterpolateRegulator.inference,
+// flow/length_regulator.py:49-70): src = (t + 0.5) * T_in / T_out - 0.5 clamped at 0, fp32 index arithmetic as ATen's.
+template <int DT>
+__global__ __launch_bounds__(256) void interp_linear_kernel(const float* x, int ldx, int T_in, void* y, int ldy, int T_out, int C) {
+  const float scale = (float)T_in / (float)T_out;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)T_out * C; i += (int64_t)gridDim.x * 256) {
+    const int t = (int)(i / C), c = (int)(i % C);
+    const float src = fmaxf(scale * ((float)t + 0.5f) - 0.5f, 0.f);
+    const int i0 = min((int)src, T_in - 1), i1 = min(i0 + 1, T_in - 1);
+    const float l1 = src - (float)i0, l0 = 1.f - l1;
+    const float v = l0 * x[(int64_t)i0 * ldx + c] + l1 * x[(int64_t)i1 * ldx + c];
+    if constexpr (DT == CV_F32) ((float*)y)[(int64_t)t * ldy + c] = v;
+    else ((uint16_t*)y)[(int64_t)t * ldy + c] = Elem16<DT>::from_f32(v);
+  }
+}
+
 inline int nblocks(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
 
 }  // namespace
@@ -103,6 +119,15 @@ extern "C" int cv_cfm_update(float* x, const float* v, int32_t B, int32_t T, int
   if (!x || !v || B <= 0 || T <= 0 || C <= 0 || ((T * C) & 3)) return CV_ERR_ARG;
   const int64_t n4 = (int64_t)T * C / 4;
   hipLaunchKernelGGL(cfm_update_kernel, dim3(nblocks((int64_t)B * n4)), dim3(256), 0, (hipStream_t)stream, x, v, B, n4, dt, cfg_rate);
+  CV_CHECK_LAUNCH();
+  return CV_OK;
+}
+
+extern "C" int cv_interp_linear_cl(const float* x, int32_t ldx, int32_t T_in, void* y, int32_t ldy, int32_t dtype, int32_t T_out,
+                                   int32_t C, void* stream) {
+  if (!x || !y || T_in <= 0 || T_out <= 0 || C <= 0 || ldx < C || ldy < C) return CV_ERR_ARG;
+  DISPATCH_DT(dtype, hipLaunchKernelGGL(interp_linear_kernel<DT>, dim3(nblocks((int64_t)T_out * C)), dim3(256), 0, (hipStream_t)stream,
+                                        x, ldx, T_in, y, ldy, T_out, C));
   CV_CHECK_LAUNCH();
   return CV_OK;
 }

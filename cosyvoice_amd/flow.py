@@ -224,26 +224,36 @@ class ConditionalDecoder:
         self._ws: Dict[tuple, dict] = {}
         self._tcache: Dict[tuple, torch.Tensor] = {}
 
+    def _load_resnet(self, P, name, norm_idx=2):
+        n = norm_idx   # Block1D: Conv1d, GroupNorm, Mish (norm at .1); CausalBlock1D has a Transpose in between (norm at .2)
+        return dict(w1=P.conv(f"{name}.block1.block.0.weight"), b1=P.f32(f"{name}.block1.block.0.bias"),
+                    g1=P.f32(f"{name}.block1.block.{n}.weight"), be1=P.f32(f"{name}.block1.block.{n}.bias"),
+                    w2=P.conv(f"{name}.block2.block.0.weight"), b2=P.f32(f"{name}.block2.block.0.bias"),
+                    g2=P.f32(f"{name}.block2.block.{n}.weight"), be2=P.f32(f"{name}.block2.block.{n}.bias"),
+                    wr=P.conv(f"{name}.res_conv.weight"), br=P.f32(f"{name}.res_conv.bias"))
+
+    def _load_tblock(self, P, sd, name):
+        wqk = torch.cat([sd[f"{name}.attn1.to_q.weight"].float(), sd[f"{name}.attn1.to_k.weight"].float()], 0)
+        return dict(g1=P.f32(f"{name}.norm1.weight"), b1=P.f32(f"{name}.norm1.bias"),
+                    wqk=wqk.to(device=self.device, dtype=self.dtype).contiguous(), wv=P.w(f"{name}.attn1.to_v.weight"),
+                    wo=P.w(f"{name}.attn1.to_out.0.weight"), bo=P.f32(f"{name}.attn1.to_out.0.bias"),
+                    g3=P.f32(f"{name}.norm3.weight"), b3=P.f32(f"{name}.norm3.bias"),
+                    wf1=P.w(f"{name}.ff.net.0.proj.weight"), bf1=P.f32(f"{name}.ff.net.0.proj.bias"),
+                    wf2=P.w(f"{name}.ff.net.2.weight"), bf2=P.f32(f"{name}.ff.net.2.bias"))
+
+    def _load_time(self, P, sd, prefix, names):
+        """time-embedding path (input independent): TimestepEmbedding + every resnet's Mish->Linear, stacked"""
+        self.t1_w, self.t1_b = P.w(f"{prefix}time_mlp.linear_1.weight"), P.f32(f"{prefix}time_mlp.linear_1.bias")
+        self.t2_w, self.t2_b = P.w(f"{prefix}time_mlp.linear_2.weight"), P.f32(f"{prefix}time_mlp.linear_2.bias")
+        self.tm_w = torch.cat([sd[f"{n}.0.mlp.1.weight"].float() for n in names], 0).to(device=self.device, dtype=self.dtype).contiguous()
+        self.tm_b = torch.cat([sd[f"{n}.0.mlp.1.bias"].float() for n in names], 0).to(device=self.device).contiguous()
+
     def load(self, sd, prefix="decoder.estimator."):
         cfg = self.cfg
         P = _P(sd, self.dtype, self.device)
         self.P = P
-
-        def resnet(name):
-            return dict(w1=P.conv(f"{name}.block1.block.0.weight"), b1=P.f32(f"{name}.block1.block.0.bias"),
-                        g1=P.f32(f"{name}.block1.block.2.weight"), be1=P.f32(f"{name}.block1.block.2.bias"),
-                        w2=P.conv(f"{name}.block2.block.0.weight"), b2=P.f32(f"{name}.block2.block.0.bias"),
-                        g2=P.f32(f"{name}.block2.block.2.weight"), be2=P.f32(f"{name}.block2.block.2.bias"),
-                        wr=P.conv(f"{name}.res_conv.weight"), br=P.f32(f"{name}.res_conv.bias"))
-
-        def tblock(name):
-            wqk = torch.cat([sd[f"{name}.attn1.to_q.weight"].float(), sd[f"{name}.attn1.to_k.weight"].float()], 0)
-            return dict(g1=P.f32(f"{name}.norm1.weight"), b1=P.f32(f"{name}.norm1.bias"),
-                        wqk=wqk.to(device=self.device, dtype=self.dtype).contiguous(), wv=P.w(f"{name}.attn1.to_v.weight"),
-                        wo=P.w(f"{name}.attn1.to_out.0.weight"), bo=P.f32(f"{name}.attn1.to_out.0.bias"),
-                        g3=P.f32(f"{name}.norm3.weight"), b3=P.f32(f"{name}.norm3.bias"),
-                        wf1=P.w(f"{name}.ff.net.0.proj.weight"), bf1=P.f32(f"{name}.ff.net.0.proj.bias"),
-                        wf2=P.w(f"{name}.ff.net.2.weight"), bf2=P.f32(f"{name}.ff.net.2.bias"))
+        resnet = lambda name: self._load_resnet(P, name)
+        tblock = lambda name: self._load_tblock(P, sd, name)
 
         names = [f"{prefix}down_blocks.0"] + [f"{prefix}mid_blocks.{i}" for i in range(cfg.est_mid_blocks)] + [f"{prefix}up_blocks.0"]
         self.blocks = [dict(res=resnet(f"{n}.0"), tb=[tblock(f"{n}.1.{j}") for j in range(cfg.est_n_blocks)]) for n in names]
@@ -252,11 +262,7 @@ class ConditionalDecoder:
         self.fin_w, self.fin_b = P.conv(f"{prefix}final_block.block.0.weight"), P.f32(f"{prefix}final_block.block.0.bias")
         self.fin_g, self.fin_be = P.f32(f"{prefix}final_block.block.2.weight"), P.f32(f"{prefix}final_block.block.2.bias")
         self.proj_w, self.proj_b = P.conv(f"{prefix}final_proj.weight"), P.f32(f"{prefix}final_proj.bias")
-        # time-embedding path (input independent): TimestepEmbedding + every resnet's Mish->Linear, stacked
-        self.t1_w, self.t1_b = P.w(f"{prefix}time_mlp.linear_1.weight"), P.f32(f"{prefix}time_mlp.linear_1.bias")
-        self.t2_w, self.t2_b = P.w(f"{prefix}time_mlp.linear_2.weight"), P.f32(f"{prefix}time_mlp.linear_2.bias")
-        self.tm_w = torch.cat([sd[f"{n}.0.mlp.1.weight"].float() for n in names], 0).to(device=self.device, dtype=self.dtype).contiguous()
-        self.tm_b = torch.cat([sd[f"{n}.0.mlp.1.bias"].float() for n in names], 0).to(device=self.device).contiguous()
+        self._load_time(P, sd, prefix, names)
 
     def time_table(self, t_values: List[float]) -> torch.Tensor:
         """(len(t), n_blocks*C) fp32: the per-resnet additive time term mlp(mish(time_mlp(sinus(t)))) for each step

@@ -41,8 +41,9 @@ class CosyVoice2Model:
         self.flow.fp16 = fp16
         self.token_hop_len = 2 * self.flow.input_frame_rate
         # model.py:313-315
-        self.flow.encoder.static_chunk_size = 2 * self.flow.input_frame_rate
-        self.flow.decoder.estimator.static_chunk_size = 2 * self.flow.input_frame_rate * self.flow.token_mel_ratio
+        if hasattr(self.flow, "token_mel_ratio"):     # CosyVoice2 flow; the v1 MaskedDiffWithXvec has no chunk attention
+            self.flow.encoder.static_chunk_size = 2 * self.flow.input_frame_rate
+            self.flow.decoder.estimator.static_chunk_size = 2 * self.flow.input_frame_rate * self.flow.token_mel_ratio
         self.mel_cache_len = 8
         self.source_cache_len = int(self.mel_cache_len * 480)
         self.speech_window = np.hamming(2 * self.source_cache_len)

@@ -199,6 +199,40 @@ def cfm_update(x, v, dt, cfg_rate):
                                   L.stream_ptr()), "cv_cfm_update")
 
 
+def groupnorm_workspace(B, T, groups, device):
+    f = L.lib().cv_groupnorm_workspace_floats
+    f.restype = C.c_int64
+    return torch.empty(int(f(B, T, groups)), device=device, dtype=torch.float32)
+
+
+def groupnorm_cl(x, groups, gamma, beta, eps, partial, *, act=ACT_NONE, add=None, out_f32=None, out_act=None):
+    """x (B, T, C) fp32 channels-last (any row / batch strides); add (C,) or (B, C) fp32 added after the activation."""
+    _req_cuda(x, gamma, beta, partial, add, out_f32, out_act)
+    B, T, Cc = x.shape
+    assert x.stride(2) == 1 and partial.numel() >= B * groups * ((T + 31) // 32) * 2
+    p = L.GroupNormParams()
+    p.B, p.T, p.C, p.groups, p.eps = B, T, Cc, groups, eps
+    p.x, p.x_bs, p.ldx = x.data_ptr(), x.stride(0), x.stride(1)
+    p.gamma, p.beta = L.ptr(gamma), L.ptr(beta)
+    p.add, p.add_ld = L.ptr(add), (add.stride(0) if add is not None and add.dim() == 2 else 0)
+    p.act = act
+    p.out_dtype = L.TORCH_DT[out_act.dtype] if out_act is not None else CV_F32
+    if out_f32 is not None:
+        p.out_f32, p.o32_bs, p.ldo32 = out_f32.data_ptr(), out_f32.stride(0), out_f32.stride(1)
+    if out_act is not None:
+        p.out_act, p.oa_bs, p.ldoa = out_act.data_ptr(), out_act.stride(0), out_act.stride(1)
+    p.partial = partial.data_ptr()
+    L.check(L.lib().cv_groupnorm_cl(C.byref(p), L.stream_ptr()), "cv_groupnorm_cl")
+
+
+def interp_linear_cl(x, y):
+    """x (T_in, C) fp32 rows (stride(0) = ld) -> y (T_out, C) any dtype: F.interpolate(mode='linear') along T."""
+    _req_cuda(x, y)
+    assert x.dtype == torch.float32 and x.shape[1] == y.shape[1] and x.stride(1) == 1 and y.stride(1) == 1
+    L.check(L.lib().cv_interp_linear_cl(C.c_void_p(x.data_ptr()), x.stride(0), x.shape[0], C.c_void_p(y.data_ptr()), y.stride(0),
+                                        L.TORCH_DT[y.dtype], y.shape[0], x.shape[1], L.stream_ptr()), "cv_interp_linear_cl")
+
+
 class Graph:
     """hipGraph of a launch sequence issued through the ABI on torch's current stream."""
 

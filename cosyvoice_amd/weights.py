@@ -172,10 +172,10 @@ def _conformer_layer(specs, name, dim, heads, units):
     _ln(specs, f"{name}.norm_mha", dim)
 
 
-def _est_resnet(specs, name, cin, cout, tdim):
+def _est_resnet(specs, name, cin, cout, tdim, norm_idx=2):
     for b, ci in (("block1", cin), ("block2", cout)):
         _conv(specs, f"{name}.{b}.block.0", cout, ci, 3)
-        _ln(specs, f"{name}.{b}.block.2", cout)
+        _ln(specs, f"{name}.{b}.block.{norm_idx}", cout)
     _linear(specs, f"{name}.mlp.1", cout, tdim)
     _conv(specs, f"{name}.res_conv", cout, cin, 1)
 
@@ -407,3 +407,61 @@ def transformer_lm_specs(cfg) -> List[Spec]:
 
 def transformer_lm_state_dict(cfg, seed: int = 1986, round_to=None):
     return materialize(transformer_lm_specs(cfg), seed, round_to)
+
+
+# --------------------------------------------------------------------------- CosyVoice-v1 flow (MaskedDiffWithXvec)
+def estimator_v1_specs(cfg, prefix: str = "decoder.estimator.") -> List[Spec]:
+    """Non-causal ConditionalDecoder channels=[C, C] (flow/decoder.py:110-206): down_blocks.0 ends in Downsample1D (`.2.conv`,
+    k3 stride 2), down_blocks.1 in a plain Conv1d, up_blocks.0 in Upsample1D (`.2.conv`, ConvTranspose1d(4,2,1)), up_blocks.1
+    in a plain Conv1d; every Block1D norm is a GroupNorm at `.block.1` (Conv1d, GroupNorm, Mish; the causal block has a Transpose in between)."""
+    s: List[Spec] = []
+    C, tdim = cfg.est_channels, cfg.est_time_dim
+    inner, ff = cfg.est_inner, cfg.est_channels * cfg.est_ff_mult
+    _linear(s, f"{prefix}time_mlp.linear_1", tdim, cfg.est_in_channels)
+    _linear(s, f"{prefix}time_mlp.linear_2", tdim, tdim)
+
+    def stage(name, cin):
+        _est_resnet(s, f"{name}.0", cin, C, tdim, norm_idx=1)
+        for j in range(cfg.est_n_blocks):
+            _est_tblock(s, f"{name}.1.{j}", C, inner, ff)
+
+    stage(f"{prefix}down_blocks.0", cfg.est_in_channels)
+    _conv(s, f"{prefix}down_blocks.0.2.conv", C, C, 3)
+    stage(f"{prefix}down_blocks.1", C)
+    _conv(s, f"{prefix}down_blocks.1.2", C, C, 3)
+    for i in range(cfg.est_mid_blocks):
+        stage(f"{prefix}mid_blocks.{i}", C)
+    stage(f"{prefix}up_blocks.0", 2 * C)
+    s.append((f"{prefix}up_blocks.0.2.conv.weight", (C, C, 4), "normal", 1.0 / math.sqrt(C * 2)))
+    s.append((f"{prefix}up_blocks.0.2.conv.bias", (C,), "normal", 0.02))
+    stage(f"{prefix}up_blocks.1", 2 * C)
+    _conv(s, f"{prefix}up_blocks.1.2", C, C, 3)
+    _conv(s, f"{prefix}final_block.block.0", C, C, 3)
+    _ln(s, f"{prefix}final_block.block.1", C)
+    _conv(s, f"{prefix}final_proj", cfg.output_size, C, 1)
+    return s
+
+
+def flow_v1_specs(cfg) -> List[Spec]:
+    """flow/flow.py:47-62 module tree: input_embedding, spk_embed_affine_layer, encoder (ConformerEncoder), encoder_proj,
+    length_regulator.model (Conv1d k3, GroupNorm, Mish) x reg_layers + Conv1d k1, decoder.estimator."""
+    s: List[Spec] = []
+    D, O = cfg.enc_dim, cfg.output_size
+    s.append(("input_embedding.weight", (cfg.vocab_size, cfg.input_size), "normal", 1.0))
+    _linear(s, "spk_embed_affine_layer", O, cfg.spk_embed_dim, gain=3.0)
+    _linear(s, "encoder.embed.out.0", D, cfg.input_size)
+    _ln(s, "encoder.embed.out.1", D)
+    _ln(s, "encoder.after_norm", D)
+    for i in range(cfg.enc_blocks):
+        _conformer_layer(s, f"encoder.encoders.{i}", D, cfg.enc_heads, cfg.enc_linear_units)
+    _linear(s, "encoder_proj", O, D)
+    for i in range(cfg.reg_layers):
+        _conv(s, f"length_regulator.model.{3 * i}", O, O, 3)
+        _ln(s, f"length_regulator.model.{3 * i + 1}", O)
+    _conv(s, f"length_regulator.model.{3 * cfg.reg_layers}", O, O, 1)
+    s += estimator_v1_specs(cfg)
+    return s
+
+
+def flow_v1_state_dict(cfg, seed: int = 1986, round_to=None):
+    return materialize(flow_v1_specs(cfg), seed, round_to)

@@ -88,6 +88,28 @@ typedef struct cv_norm_params {
 int cv_layernorm(const cv_norm_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * cv_groupnorm_cl — nn.GroupNorm(groups, C) on a channels-last fp32 tensor [B][T][C] (statistics over T x C/groups),
+ * fused affine, optional Mish, optional per-batch-row vector added after the activation (time embedding).
+ * Replaces Block1D's GroupNorm+Mish of the non-causal CFM estimator (matcha decoder Block1D via flow/decoder.py:129-130,
+ * CosyVoice-v1) and InterpolateRegulator's GroupNorm (flow/length_regulator.py:36-38).  Two launches (chunk statistics,
+ * merge + apply); `partial` is caller-owned scratch of cv_groupnorm_workspace_floats(B, T, groups) floats.
+ * x may alias out_f32.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cv_groupnorm_params {
+  int32_t B, T, C, groups; float eps;
+  const float* x; int64_t x_bs; int32_t ldx;
+  const float* gamma; const float* beta;
+  const float* add; int32_t add_ld;
+  int32_t act;            /* CV_ACT_NONE or CV_ACT_MISH */
+  int32_t out_dtype;      /* dtype of out_act */
+  float* out_f32; int64_t o32_bs; int32_t ldo32;
+  void* out_act; int64_t oa_bs; int32_t ldoa;
+  float* partial;
+} cv_groupnorm_params;
+int64_t cv_groupnorm_workspace_floats(int32_t B, int32_t T, int32_t groups);
+int cv_groupnorm_cl(const cv_groupnorm_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * cv_attention — flash attention, head_dim 64, 16-bit operands, fp32 softmax/accumulate.
  *   S[i][j] = scale * q_i . k_j + bias[i][j];  masks: j < klen[b]; chunk: j < (i/chunk+1)*chunk; causal: j <= i + causal_off
  * Q [B][Tq][ldq] (head h at column h*64), K [B][Tk][ldk] (kv head at column hk*64),
@@ -152,6 +174,10 @@ int cv_est_pack(const float* x, const float* mu, const float* spks, const float*
                 int32_t B, int32_t T, int32_t C, void* stream);
 /* Euler step with CFG: x += dt * ((1+w) * v[2b] - w * v[2b+1]);  v [2B][T][C] fp32 (flow_matching.py:116-118) */
 int cv_cfm_update(float* x, const float* v, int32_t B, int32_t T, int32_t C, float dt, float cfg_rate, void* stream);
+/* F.interpolate(mode="linear", align_corners=False) along T, channels-last: x [T_in][ldx] fp32 -> y [T_out][ldy] `dtype`
+ * (InterpolateRegulator.inference, flow/length_regulator.py:49-70). */
+int cv_interp_linear_cl(const float* x, int32_t ldx, int32_t T_in, void* y, int32_t ldy, int32_t dtype, int32_t T_out,
+                        int32_t C, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Prompt-feature front half: mel_spectrogram (cosyvoice/dataset/processor_kaldidata.py:37-74; 24 kHz: n_fft = win 1920,

@@ -506,6 +506,26 @@ def golden_v1_orchestrator():
     save("v1_orchestrator", source_speech_token=src, prompt_token=ptok, prompt_feat=pfeat, embedding=emb,
          stream_chunk_samples=out["stream"], full_samples=out["full"])
 
+    # the genuine v1 stack: reference MaskedDiffWithXvec (50 Hz tokens, flow cache) + HiFT v1 under the same orchestrator
+    from cosyvoice_amd.config import FlowV1Config
+    from cosyvoice_amd.weights import flow_v1_state_dict
+    f1 = FlowV1Config.tiny()
+    m = CosyVoiceModel(_NoLLM(), build_ref_flow_v1(f1, flow_v1_state_dict(f1)), hift, fp16=False, sr=22050)
+    m.device = torch.device("cpu")
+    src = torch.randint(0, f1.vocab_size, (1, 330), generator=g, dtype=torch.int32)
+    ptok = torch.randint(0, f1.vocab_size, (1, 2 * n_p), generator=g, dtype=torch.int32)
+    pfeat = torch.clamp(torch.randn(1, 20, 80, generator=g) * 2 - 6, -11.5, 2.0)
+    out = {}
+    for stream in (True, False):
+        torch.manual_seed(0)
+        with torch.inference_mode():
+            chunks = [o["tts_speech"] for o in m.vc(src, ptok, pfeat, emb, stream=stream)]
+        out["stream" if stream else "full"] = np.array([c.shape[1] for c in chunks], dtype=np.int64)
+        assert all(torch.isfinite(c).all() for c in chunks)
+    save("v1_orchestrator_v1flow", source_speech_token=src, prompt_token=ptok, prompt_feat=pfeat, embedding=emb,
+         stream_chunk_samples=out["stream"], full_samples=out["full"], token_min_hop_len=np.array(m.token_min_hop_len),
+         mel_overlap_len=np.array(m.mel_overlap_len))
+
 
 def golden_llm_v1():
     """CosyVoice-v1 TransformerLM (llm/llm.py:41-237): the reference module itself (reference ConformerEncoder text encoder,
@@ -557,11 +577,81 @@ def golden_llm_v1():
          embedding=emb, forced=np.array(forced, dtype=np.int32), logp=torch.stack(rows), seed=np.array(41))
 
 
+def build_ref_flow_v1(cfg, sd):
+    from omegaconf import DictConfig
+    from cosyvoice.flow.decoder import ConditionalDecoder
+    from cosyvoice.flow.flow import MaskedDiffWithXvec
+    from cosyvoice.flow.flow_matching import ConditionalCFM
+    from cosyvoice.flow.length_regulator import InterpolateRegulator
+    from cosyvoice.transformer.encoder import ConformerEncoder
+    enc = ConformerEncoder(output_size=cfg.enc_dim, attention_heads=cfg.enc_heads, linear_units=cfg.enc_linear_units,
+                           num_blocks=cfg.enc_blocks, dropout_rate=0.1, positional_dropout_rate=0.1, attention_dropout_rate=0.1,
+                           normalize_before=True, input_layer="linear", pos_enc_layer_type="rel_pos_espnet",
+                           selfattention_layer_type="rel_selfattn", input_size=cfg.input_size, use_cnn_module=False,
+                           macaron_style=False)
+    est = ConditionalDecoder(in_channels=cfg.est_in_channels, out_channels=cfg.output_size, channels=[cfg.est_channels] * 2,
+                             dropout=0.0, attention_head_dim=cfg.est_head_dim, n_blocks=cfg.est_n_blocks,
+                             num_mid_blocks=cfg.est_mid_blocks, num_heads=cfg.est_heads, act_fn="gelu")
+    cfm = ConditionalCFM(in_channels=240, n_spks=1, spk_emb_dim=80,
+                         cfm_params=DictConfig({"sigma_min": 1e-06, "solver": "euler", "t_scheduler": "cosine",
+                                                "training_cfg_rate": 0.2, "inference_cfg_rate": cfg.inference_cfg_rate,
+                                                "reg_loss_type": "l1"}), estimator=est)
+    flow = MaskedDiffWithXvec(input_size=cfg.input_size, output_size=cfg.output_size, spk_embed_dim=cfg.spk_embed_dim,
+                              output_type="mel", vocab_size=cfg.vocab_size, input_frame_rate=cfg.input_frame_rate,
+                              only_mask_loss=True, encoder=enc,
+                              length_regulator=InterpolateRegulator(channels=cfg.output_size, sampling_ratios=[1] * cfg.reg_layers),
+                              decoder=cfm)
+    flow.load_state_dict(sd, strict=True)
+    return flow.eval()
+
+
+def golden_flow_v1():
+    """CosyVoice-v1 MaskedDiffWithXvec (flow/flow.py:25-160): the reference modules themselves — ConformerEncoder,
+    InterpolateRegulator, ConditionalCFM with its flow cache, non-causal ConditionalDecoder channels=[C, C] (through the same
+    restated diffusers classes as golden_flow) — on key-seeded weights.  The torch.randn_like draw of flow_matching.py:56 is
+    reproduced by re-seeding the global generator (checked against the z half of the returned flow cache)."""
+    from cosyvoice_amd.config import FlowV1Config
+    from cosyvoice_amd.weights import flow_v1_state_dict
+    cfg = FlowV1Config.tiny()
+    flow = build_ref_flow_v1(cfg, flow_v1_state_dict(cfg))
+    est = flow.decoder.estimator
+    g = torch.Generator().manual_seed(33)
+    sr = 22050
+    n_p, n_g1, n_g2, t1 = 12, 50, 30, 20
+    prompt_token = torch.randint(0, cfg.vocab_size, (1, n_p), generator=g, dtype=torch.int32)
+    token1 = torch.randint(0, cfg.vocab_size, (1, n_g1), generator=g, dtype=torch.int32)
+    token2 = torch.randint(0, cfg.vocab_size, (1, n_g2), generator=g, dtype=torch.int32)
+    prompt_feat = torch.clamp(torch.randn(1, t1, 80, generator=g) * 2 - 6, -11.5, 2.0)
+    embedding = torch.randn(1, cfg.spk_embed_dim, generator=g)
+
+    def call(token, cache, seed):
+        torch.manual_seed(seed)
+        mel, new_cache = flow.inference(token=token, token_len=torch.tensor([token.shape[1]]), prompt_token=prompt_token,
+                                        prompt_token_len=torch.tensor([n_p]), prompt_feat=prompt_feat,
+                                        prompt_feat_len=torch.tensor([t1]), embedding=embedding, flow_cache=cache, sample_rate=sr)
+        torch.manual_seed(seed)
+        z = torch.randn(1, 80, t1 + mel.shape[2])
+        return mel, new_cache, z
+
+    with torch.inference_mode():
+        mel1, cache1, z1 = call(token1, torch.zeros(1, 80, 0, 2), 101)
+        assert torch.equal(cache1[:, :, :t1, 0], z1[:, :, :t1]) and torch.equal(cache1[:, :, t1:, 0], z1[:, :, -34:])
+        mel2, cache2, z2 = call(token2, cache1, 102)          # T = 71 (odd): the up path slices the transposed conv's extra frame
+        T = 37
+        x = torch.randn(2, 80, T, generator=g); mu = torch.randn(2, 80, T, generator=g)
+        cond = torch.randn(2, 80, T, generator=g); spks = torch.randn(2, 80, generator=g)
+        t = torch.tensor([0.45, 0.45])
+        est_out = est(x, torch.ones(2, 1, T), mu, t, spks, cond)
+    save("flow_v1_tiny", prompt_token=prompt_token, token1=token1, token2=token2, prompt_feat=prompt_feat, embedding=embedding,
+         sample_rate=np.array(sr), z1=z1, mel1=mel1, cache1=cache1, z2=z2, mel2=mel2, cache2=cache2,
+         est_x=x, est_mu=mu, est_cond=cond, est_spks=spks, est_t=t, est_out=est_out)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     install_stubs()
-    which = sys.argv[1:] or ["hift", "flow", "llm", "bigvgan", "frontend", "phoneme", "v1orch", "llmv1"]
+    which = sys.argv[1:] or ["hift", "flow", "llm", "bigvgan", "frontend", "phoneme", "v1orch", "llmv1", "flowv1"]
     if "hift" in which:
         golden_hift()
     if "flow" in which:
@@ -579,6 +669,8 @@ def main():
         golden_v1_orchestrator()
     if "llmv1" in which:
         golden_llm_v1()
+    if "flowv1" in which:
+        golden_flow_v1()
 
 
 if __name__ == "__main__":

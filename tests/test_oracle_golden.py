@@ -182,3 +182,28 @@ def test_v1_transformer_lm_vs_reference(golden_dir):
     fin = torch.isfinite(g["logp"])
     assert lp.shape == g["logp"].shape and (torch.isinf(lp) == ~fin).all()
     assert (lp[fin] - g["logp"][fin]).abs().max().item() < 1e-4
+
+
+def test_v1_flow_vs_reference(golden_dir):
+    """oracle.flow_v1 against the reference's own MaskedDiffWithXvec (ConformerEncoder, InterpolateRegulator, ConditionalCFM
+    with its flow cache, non-causal two-level estimator): a first chunk with an empty cache (head/mid/tail interpolation) and a
+    second chunk that inherits the cache (odd mel length: the transposed conv's extra frame is sliced)."""
+    from cosyvoice_amd.config import FlowV1Config
+    from cosyvoice_amd.weights import flow_v1_state_dict
+    from oracle import flow_v1 as o
+    g = _load(golden_dir, "flow_v1_tiny")
+    c = FlowV1Config.tiny()
+    sd = flow_v1_state_dict(c)
+    sr = int(g["sample_rate"])
+    with torch.no_grad():
+        est = o.estimator_forward(sd, c, g["est_x"], g["est_mu"], g["est_t"], g["est_spks"], g["est_cond"])
+        assert (est - g["est_out"]).abs().max().item() < 2e-4
+        mel1, cache1 = o.inference(sd, c, g["token1"], g["prompt_token"], g["prompt_feat"], g["embedding"],
+                                   torch.zeros(1, 80, 0, 2), sr, g["z1"])
+        assert mel1.shape == g["mel1"].shape and (mel1 - g["mel1"]).abs().max().item() < 5e-4
+        assert (cache1 - g["cache1"]).abs().max().item() < 1e-4
+        mel2, cache2 = o.inference(sd, c, g["token2"], g["prompt_token"], g["prompt_feat"], g["embedding"], g["cache1"], sr, g["z2"])
+        assert mel2.shape == g["mel2"].shape and (mel2 - g["mel2"]).abs().max().item() < 5e-4
+        assert (cache2 - g["cache2"]).abs().max().item() < 1e-4
+    print(f"v1 flow oracle vs reference: est {float((est - g['est_out']).abs().max()):.2e}, mel1 {float((mel1 - g['mel1']).abs().max()):.2e}, "
+          f"mel2 {float((mel2 - g['mel2']).abs().max()):.2e}")
