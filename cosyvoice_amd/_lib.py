@@ -124,7 +124,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.cv_arch.restype = C.c_char_p
         for name, st in (("gemm", GemmParams), ("norm", NormParams), ("attn", AttnParams), ("skinny", SkinnyParams),
-                         ("sample", SampleParams)):
+                         ("sample", SampleParams), ("groupnorm", GroupNormParams)):
             fn = getattr(_lib, f"cv_sizeof_{name}_params")
             if fn() != C.sizeof(st):
                 raise RuntimeError(f"ABI mismatch for cv_{name}_params: C {fn()} vs ctypes {C.sizeof(st)}")
@@ -139,7 +139,7 @@ EXPORTS = ["cv_version", "cv_arch", "cv_gemm", "cv_layernorm", "cv_attention",
            "cv_stream_destroy", "cv_skinny_gemm", "cv_pack_skinny", "cv_rmsnorm_reduce", "cv_rope_append",
            "cv_decode_attention", "cv_sample_ras", "cv_sizeof_skinny_params", "cv_sizeof_sample_params", "cv_anti_alias_act", "cv_anti_alias_act_cl",
            "cv_stft_magnitude", "cv_log_clamp_channels_first", "cv_groupnorm_cl", "cv_groupnorm_workspace_floats",
-           "cv_interp_linear_cl"]
+           "cv_interp_linear_cl", "cv_sizeof_groupnorm_params", "cv_relpos_append"]
 
 TORCH_DT = {torch.float32: CV_F32, torch.bfloat16: CV_BF16, torch.float16: CV_F16}
 DT_TORCH = {v: k for k, v in TORCH_DT.items()}

@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256, ((TPW == 2 && TPR >= 32) ? 3 : 2)) void skinny
       float o = v[t][r];
       if (p.bias && blockIdx.y == 0) o += p.bias[n];
       if (p.mode == 1) p.out_f32[(int64_t)m * p.ldo + n] = resid[t][r] + o;
+      else if (p.mode == 3) ((uint16_t*)p.out_act)[(int64_t)m * p.ldoa + n] = Elem16<DT>::from_f32(fmaxf(o, 0.f));
       else p.out_f32[(int64_t)blockIdx.y * p.slab_stride + (int64_t)m * p.ldo + n] = o;
     }
   }
@@ -1136,6 +1137,9 @@ extern "C" int cv_skinny_gemm(const cv_skinny_params* pp, void* stream) {
   const int tpw = p.mode == 2 ? 2 : 1;
   if (p.mode == 2) {
     if (p.ksplit != 1 || (ntiles & 1) || !p.out_act || (p.ldoa & 3)) return CV_ERR_ARG;
+  } else if (p.mode == 3) {
+    if (p.ksplit != 1 || !p.out_act || norm) return CV_ERR_ARG;
+    p.max_wgs = 0;   // single-shot kernel only
   } else {
     if (!p.out_f32) return CV_ERR_ARG;
     if (p.mode == 1 && p.ksplit != 1) return CV_ERR_ARG;
@@ -1204,6 +1208,34 @@ extern "C" int cv_rmsnorm_reduce(float* x, int32_t ldx, const float* slabs, int3
     case CV_F32: hipLaunchKernelGGL(rmsnorm_reduce_kernel<CV_F32>, dim3(rows), dim3(256), 0, st, x, ldx, slabs, nslab, slab_stride, ld_slab, gamma, eps, xn, ldxn, dim); break;
     case CV_BF16: hipLaunchKernelGGL(rmsnorm_reduce_kernel<CV_BF16>, dim3(rows), dim3(256), 0, st, x, ldx, slabs, nslab, slab_stride, ld_slab, gamma, eps, xn, ldxn, dim); break;
     case CV_F16: hipLaunchKernelGGL(rmsnorm_reduce_kernel<CV_F16>, dim3(rows), dim3(256), 0, st, x, ldx, slabs, nslab, slab_stride, ld_slab, gamma, eps, xn, ldxn, dim); break;
+    default: return CV_ERR_ARG;
+  }
+  CV_CHECK_LAUNCH();
+  return CV_OK;
+}
+
+namespace {
+// CosyVoice-v1 TransformerLM cached decode step: the fp32 projection row [q + pos_bias_u | q + pos_bias_v | k | v] (4 D) of the
+// new token t -> 16-bit query pair, K cache row t, V^T cache column t (TransformerEncoder.forward_chunk's att_cache append,
+// transformer/encoder.py:185-274, transformer/attention.py:249-330).
+template <int DT>
+__global__ __launch_bounds__(256) void relpos_append_kernel(const float* qkv, void* qq, void* kc, void* vtc, int D, int t, int vt_ld) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 4 * D) return;
+  const uint16_t v = Elem16<DT>::from_f32(qkv[i]);
+  if (i < 2 * D) ((uint16_t*)qq)[i] = v;
+  else if (i < 3 * D) ((uint16_t*)kc)[(int64_t)t * D + (i - 2 * D)] = v;
+  else ((uint16_t*)vtc)[(int64_t)(i - 3 * D) * vt_ld + t] = v;
+}
+}  // namespace
+
+extern "C" int cv_relpos_append(const float* qkv, void* qq, void* kcache, void* vtcache, int32_t dtype, int32_t D, int32_t t,
+                                int32_t vt_ld, void* stream) {
+  if (!qkv || !qq || !kcache || !vtcache || D <= 0 || t < 0 || t >= vt_ld) return CV_ERR_ARG;
+  dim3 grid((4 * D + 255) / 256);
+  switch (dtype) {
+    case CV_BF16: hipLaunchKernelGGL(relpos_append_kernel<CV_BF16>, grid, dim3(256), 0, (hipStream_t)stream, qkv, qq, kcache, vtcache, D, t, vt_ld); break;
+    case CV_F16: hipLaunchKernelGGL(relpos_append_kernel<CV_F16>, grid, dim3(256), 0, (hipStream_t)stream, qkv, qq, kcache, vtcache, D, t, vt_ld); break;
     default: return CV_ERR_ARG;
   }
   CV_CHECK_LAUNCH();

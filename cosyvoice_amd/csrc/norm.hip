@@ -148,6 +148,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const cv_groupnorm_params
 
 }  // namespace
 
+extern "C" int cv_sizeof_groupnorm_params(void) { return (int)sizeof(cv_groupnorm_params); }
+
 extern "C" int64_t cv_groupnorm_workspace_floats(int32_t B, int32_t T, int32_t groups) {
   if (B <= 0 || T <= 0 || groups <= 0) return 0;
   return (int64_t)B * groups * ((T + GN_ROWS - 1) / GN_ROWS) * 2;

@@ -36,6 +36,42 @@ class f32_products:
         _tls.f32_mode = self.prev
 
 
+class Recorder:
+    """Collects the parameter blocks of cv_gemm / cv_layernorm / cv_attention calls instead of launching them, so a fixed
+    launch sequence (the v1 LM's cached decode step) is built once and re-issued with a few patched fields per step: the
+    Python cost of a launch drops from filling a 50-field struct to one foreign call."""
+
+    def __init__(self):
+        self.calls = []          # [(entry point name, params struct)]
+
+    def __enter__(self):
+        self._prev = getattr(_tls, "recorder", None)
+        _tls.recorder = self
+        return self
+
+    def __exit__(self, *exc):
+        _tls.recorder = self._prev
+
+    def add_raw(self, name, args):
+        """A launch with positional arguments (a mutable list the owner may patch; the stream is appended at replay)."""
+        self.calls.append((name, args))
+
+    def replay(self):
+        lib, st = L.lib(), L.stream_ptr()
+        for name, p in self.calls:
+            rc = getattr(lib, name)(*p, st) if isinstance(p, list) else getattr(lib, name)(C.byref(p), st)
+            if rc != 0:
+                raise RuntimeError(f"{name} failed with cv_status {rc}")
+
+
+def _issue(name, p):
+    rec = getattr(_tls, "recorder", None)
+    if rec is not None:
+        rec.calls.append((name, p))
+        return
+    L.check(getattr(L.lib(), name)(C.byref(p), L.stream_ptr()), name)
+
+
 def gemm(A, W, M, N, K, *, dtype=None, batch=1, batch_inner=0, a_bs=(0, 0), lda=None, a_rows=0, cin=0,
          a_row_stride=1, tap_base=0, tap_step=0, w_bs=(0, 0), ldw=None, bias=None, res=None, res_bs=(0, 0), ldres=0,
          res2=None, ldres2=0, out_scale=1.0, act=ACT_NONE, act_param=None, act_slope=0.0, out_f32=None, o32_bs=(0, 0),
@@ -61,7 +97,7 @@ def gemm(A, W, M, N, K, *, dtype=None, batch=1, batch_inner=0, a_bs=(0, 0), lda=
         p.q_cols, p.k_cols, p.q_scale = qkv["q_cols"], qkv["k_cols"], qkv.get("q_scale", 1.0)
         p.k_out, p.k_bs, p.ldk = qkv["k_out"].data_ptr(), qkv["k_bs"], qkv["ldk"]
         p.vt_out, p.vt_heads, p.vt_ld = qkv["vt_out"].data_ptr(), qkv["vt_heads"], qkv["vt_ld"]
-    L.check(L.lib().cv_gemm(C.byref(p), L.stream_ptr()), "cv_gemm")
+    _issue("cv_gemm", p)
 
 
 def linear(x, W, *, bias=None, res=None, act=ACT_NONE, act_param=None, act_slope=0.0, out_f32=None, out_act=None,
@@ -105,7 +141,7 @@ def layernorm(x, gamma, beta, eps, *, rms=False, add=None, rows_per_group=0, act
     p.out_dtype = L.TORCH_DT[out_act.dtype] if out_act is not None else CV_F32
     p.out_f32, p.ldo32 = L.ptr(out_f32), (out_f32.stride(0) if out_f32 is not None else 0)
     p.out_act, p.ldoa = L.ptr(out_act), (out_act.stride(0) if out_act is not None else 0)
-    L.check(L.lib().cv_layernorm(C.byref(p), L.stream_ptr()), "cv_layernorm")
+    _issue("cv_layernorm", p)
 
 
 def attention(q, k, vt, out, *, H, Hkv, Tq, Tk, scale, q_bs, ldq, k_bs, ldk, vt_ld, o_bs, ldo, B, klen=None, chunk=0,
@@ -121,7 +157,7 @@ def attention(q, k, vt, out, *, H, Hkv, Tq, Tk, scale, q_bs, ldq, k_bs, ldk, vt_
     p.scale, p.klen, p.chunk, p.causal, p.causal_off = scale, L.ptr(klen), chunk, int(causal), causal_off
     p.bias, p.bias_bs, p.bias_hs, p.bias_ld = L.ptr(bias), bias_bs, bias_hs, bias_ld
     p.q_hs, p.k_hs = q_hs, k_hs
-    L.check(L.lib().cv_attention(C.byref(p), L.stream_ptr()), "cv_attention")
+    _issue("cv_attention", p)
 
 
 # ----------------------------------------------------------------------------- layout / HiFT helpers
@@ -332,7 +368,7 @@ def skinny_gemm(A, Wp, M, N, K, *, bias=None, ksplit=1, mode=0, out_f32=None, ld
         p.ngamma, p.neps = norm["gamma"].data_ptr(), norm["eps"]
         p.nx_out = L.ptr(norm.get("x_out"))
     p.max_wgs = max_wgs
-    L.check(L.lib().cv_skinny_gemm(C.byref(p), L.stream_ptr()), "cv_skinny_gemm")
+    _issue("cv_skinny_gemm", p)
 
 
 def rmsnorm_reduce(x, gamma, eps, xn, rows, *, slabs=None, nslab=0, slab_stride=0, ld_slab=0):

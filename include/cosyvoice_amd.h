@@ -106,6 +106,7 @@ typedef struct cv_groupnorm_params {
   void* out_act; int64_t oa_bs; int32_t ldoa;
   float* partial;
 } cv_groupnorm_params;
+int cv_sizeof_groupnorm_params(void);
 int64_t cv_groupnorm_workspace_floats(int32_t B, int32_t T, int32_t groups);
 int cv_groupnorm_cl(const cv_groupnorm_params* p, void* stream);
 
@@ -216,7 +217,8 @@ int cv_stream_destroy(void* stream);
  * (HBM-bound weight streaming).  A: [16][lda] 16-bit (rows >= M must be finite, e.g. zero).
  * mode 0: out_f32[ks][m][n] (+bias on slice 0), ksplit slabs of slab_stride floats;
  * mode 1: out_f32[m][n] += acc + bias (in-place residual, ksplit must be 1);
- * mode 2: SwiGLU: tiles alternate [gate16 | up16]; out_act[m][16*pair + i] = silu(g) * u (ksplit must be 1). */
+ * mode 2: SwiGLU: tiles alternate [gate16 | up16]; out_act[m][16*pair + i] = silu(g) * u (ksplit must be 1);
+ * mode 3: out_act[m][n] = T(relu(acc + bias)) (ksplit must be 1; the v1 TransformerEncoderLayer's FFN, encoder_layer.py:24-115). */
 typedef struct cv_skinny_params {
   int32_t dtype, M, N, K;
   const void* A; int32_t lda;
@@ -236,6 +238,11 @@ typedef struct cv_skinny_params {
   int32_t max_wgs;
 } cv_skinny_params;
 int cv_skinny_gemm(const cv_skinny_params* p, void* stream);
+/* CosyVoice-v1 TransformerLM cached decode step (TransformerEncoder.forward_chunk's att_cache, transformer/encoder.py:185-274):
+ * the new token's fp32 projection row qkv = [q + pos_bias_u | q + pos_bias_v | k | v] (4 D) -> qq [2 D] `dtype`, K cache row t
+ * (kcache [ctx][D]) and V^T cache column t (vtcache [D][vt_ld], row = head * 64 + channel). */
+int cv_relpos_append(const float* qkv, void* qq, void* kcache, void* vtcache, int32_t dtype, int32_t D, int32_t t,
+                     int32_t vt_ld, void* stream);
 /* W [N][K] row-major 16-bit (device) -> packed (device), N padded up to a multiple of 16 with zeros.
  * interleave != 0: rows are taken as [gate(N/2) ; up(N/2)] and emitted as alternating 16-row blocks. */
 int cv_pack_skinny(const void* W, void* Wp, int32_t N, int32_t K, int32_t interleave, void* stream);
