@@ -165,3 +165,30 @@ def test_v1_stack_orchestrator(golden_dir):
     n = outs[0].shape[1]
     assert len(outs) == 1 and n % 256 == 0 and torch.isfinite(outs[0]).all()
     assert flow.mel_len(2 * 6, 22050) <= n // 256 <= flow.mel_len(20 * 6, 22050)
+
+
+def test_empty_prompt_and_short_chunk_vs_oracle():
+    """Edge cases of flow.py:130-148 / length_regulator.py:49-70: no prompt at all (x1 empty, cond all zeros, cache = last 34
+    frames only) and a chunk of <= 40 tokens (single interpolation), then a second call inheriting that cache."""
+    from cosyvoice_amd.flow_v1 import MaskedDiffWithXvec
+    from oracle import flow_v1 as o
+    c = FlowV1Config.tiny()
+    sd = flow_v1_state_dict(c)
+    m = MaskedDiffWithXvec(c, dtype=torch.float16).load_state_dict(sd)
+    g = torch.Generator().manual_seed(9)
+    sr = 22050
+    emb = torch.randn(1, c.spk_embed_dim, generator=g)
+    ptok, pfeat = torch.zeros(1, 0, dtype=torch.int32), torch.zeros(1, 0, 80)
+    cache = ref_cache = torch.zeros(1, 80, 0, 2)
+    for n_g in (33, 47):
+        tok = torch.randint(0, c.vocab_size, (1, n_g), generator=g, dtype=torch.int32)
+        z = torch.randn(1, 80, m.mel_len(n_g, sr), generator=g)
+        with torch.no_grad():
+            ref, ref_cache = o.inference(sd, c, tok, ptok, pfeat, emb, ref_cache, sr, z)
+        mel, cache = m.inference(token=tok, token_len=torch.tensor([n_g]), prompt_token=ptok, prompt_token_len=torch.tensor([0]),
+                                 prompt_feat=pfeat, prompt_feat_len=torch.tensor([0]), embedding=emb, flow_cache=cache, sample_rate=sr, z=z)
+        assert mel.shape == ref.shape and cache.shape == ref_cache.shape == (1, 80, 34, 2)
+        err = (mel.cpu() - ref).abs()
+        assert err.mean().item() < 2e-3 and err.max().item() < 2e-2
+        assert torch.equal(cache[..., 0].cpu(), ref_cache[..., 0]) and (cache[..., 1].cpu() - ref_cache[..., 1]).abs().max().item() < 2e-2
+        cache = ref_cache.clone()
