@@ -100,6 +100,8 @@ def main():
                     help="CU slots per XCD (of 32) owned by the decode loops while they overlap flow+HiFT; 0 = no partition")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo only to rehearse the multi-process path with several ranks on ONE GPU")
+    ap.add_argument("--llm-merge", type=int, default=2,
+                    help="consecutive 8-utterance batches decoded by one token loop (2: 16 rows share every weight stream)")
     ap.add_argument("--llm-loops", type=int, default=2,
                     help="concurrent decode loops (one utterance batch each, own KV caches) on the decode CUs")
     args = ap.parse_args()
@@ -133,10 +135,11 @@ def main():
     lsd, fsd, hsd = llm_state_dict(lc), flow_state_dict(fc), hift_state_dict(hc)
     log(f"[rank {rank}] synthetic weights generated in {time.time()-t0:.1f}s")
     fdt = torch.float16 if args.flow_dtype == "fp16" else torch.bfloat16
-    llm = Qwen2LM(lc, dtype=torch.bfloat16, max_batch=UTT_PER_GPU, ctx_max=704, max_out=N_GEN + 8)
+    llm = Qwen2LM(lc, dtype=torch.bfloat16, max_batch=UTT_PER_GPU * max(1, args.llm_merge), ctx_max=704, max_out=N_GEN + 8)
     flow = CausalMaskedDiffWithXvec(fc, dtype=fdt)
     hift = HiFTGenerator(hc, dtype=torch.float32)
     model = CosyVoice2Model(llm, flow, hift, fp16=False).load_state_dicts(lsd, fsd, hsd)
+    model.llm_merge = max(1, args.llm_merge)
     # the fork drives CosyVoice2 modules through CosyVoiceModel wiring (full attention, model.py:50); the benchmark keeps
     # CosyVoice2Model's own chunk-50 encoder mask (model.py:314)
     flow.decoder.use_graph = True
@@ -211,7 +214,7 @@ def main():
         b1 = {"latency_ms": round(lat * 1e3, 2), "rtf": round(lat / AUDIO_S_PER_UTT, 5), "audio_s_per_s": round(AUDIO_S_PER_UTT / lat, 2)}
 
     # ---- roofline of the dominant kernel, measured live with events on the launch stream
-    roof = measure_roofline(llm, lc)
+    roof = measure_roofline(llm, lc, rows=min(llm.max_batch, UTT_PER_GPU * max(1, args.llm_merge)))
 
     out = None
     if rank == 0:
@@ -226,7 +229,7 @@ def main():
             "config": {"workload": "C4 full LLM->flow->HiFT pipeline, 8 utterances x 10 s per GPU, 10 s prompt "
                                    "(prefill 282, N_g 250, flow T 1000 x 10 CFG Euler steps, HiFT 500 frames)",
                        "utterances_per_gpu": B, "rtf": round(elapsed / audio_s, 6), "parallelism": f"utterance-parallel x{world}",
-                       "llm_cu_slots_per_xcd": args.llm_cu_slots, "llm_decode_loops": args.llm_loops, "batch1": b1},
+                       "llm_cu_slots_per_xcd": args.llm_cu_slots, "llm_decode_loops": args.llm_loops, "batches_per_decode_loop": args.llm_merge, "batch1": b1},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -237,15 +240,16 @@ def main():
         dist.destroy_process_group()
 
 
-def measure_roofline(llm, lc):
+def measure_roofline(llm, lc, rows=UTT_PER_GPU):
     """Roofline kernel = the decode step's gate/up skinny GEMM (exactly one shape in this workload, so the rocprof
     per-kernel average and this live measurement describe the same launches): it streams the layer's 2*4864*896 bf16
-    gate/up weights once per launch for all 8 sequences — the largest weight stream of the HBM-bound decode stage (47 % of
-    kernel time).  Algorithmic bytes per launch: DESIGN.md §6."""
+    gate/up weights once per launch for all ``rows`` sequences of a token loop (8 utterances x the batches one decode loop
+    carries) — the largest weight stream of the HBM-bound decode stage (47 % of kernel time).  Algorithmic bytes per launch:
+    DESIGN.md §6."""
     from cosyvoice_amd import ops
     st, lay = llm.st, llm.layers
     H, I = lc.hidden_size, lc.intermediate_size
-    B = UTT_PER_GPU
+    B = rows
     n_iter = 50
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -266,13 +270,18 @@ def measure_roofline(llm, lc):
     dur = ev0.elapsed_time(ev1) * 1e-3 / (n_iter * len(lay))
     alg = 2 * I * H * 2 + B * H * 4 + H * 4 + B * I * 2   # packed bf16 weights + fp32 residual rows + gamma + bf16 SwiGLU out
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_roofline_pmc.json")
+    pmc = os.path.join(ROOT, "profiles", "r01_roofline_pmc.json" if B <= 8 else "r01_roofline_pmc_b16.json")
     if os.path.exists(pmc):  # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/roofline_pmc.py)
         try:
             traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
-    return {"bound": "hbm", "kernel": "skinny_kernel<bf16,TPW=2,norm,TPR=32,U=7> (decode gate/up + RMSNorm prologue + SwiGLU)",
+    note = None
+    if B > UTT_PER_GPU:
+        note = (f"one launch streams the layer's gate/up weights for {B} sequences ({B // UTT_PER_GPU} batches share a token loop); "
+                "the 8-row form of the same kernel (one batch per loop, --llm-merge 1) runs 7.4 us = 0.295 of peak: the fused "
+                "RMSNorm prologue costs 2.0 us at 16 rows against 0.8 us at 8 (tools/roofline_time.py)")
+    return {"note": note, "bound": "hbm", "kernel": f"skinny_kernel<bf16,TPW=2,norm,TPR={32 if B <= 8 else 16},U=7> (decode gate/up + RMSNorm prologue + SwiGLU), {B} rows",
             "achieved": round(alg / dur / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg / dur / 8e12, 4),
             "traffic": traffic, "bytes_per_launch": alg, "avg_launch_us": round(dur * 1e6, 3)}
 

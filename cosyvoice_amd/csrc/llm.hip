@@ -1174,7 +1174,7 @@ extern "C" int cv_skinny_gemm(const cv_skinny_params* pp, void* stream) {
   do {                                                                                                                     \
     if (tpr == 64) { SK_LAUNCH(TPW_, NM_, 64, 8); }                                                                        \
     else if (tpr == 32) { if (exact7) { SK_LAUNCH7(TPW_, NM_, 32); } else { SK_LAUNCH(TPW_, NM_, 32, 8); } }               \
-    else { SK_LAUNCH(TPW_, NM_, 16, 8); }                                                                                  \
+    else { if (exact7) { SK_LAUNCH7(TPW_, NM_, 16); } else { SK_LAUNCH(TPW_, NM_, 16, 8); } }                               \
   } while (0)
 #define SK_NORM(TPW_)                          \
   do {                                         \

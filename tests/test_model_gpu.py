@@ -75,7 +75,8 @@ def test_tts_batch_matches_single_with_forced_tokens():
 @pytest.mark.gpu
 def test_tts_batches_cu_partition_equals_shared_streams():
     """The CU-partitioned pipeline (decode loop and flow/HiFT on disjoint CU-masked streams, graphs replayed launch by
-    launch from two host threads) produces bit-identical waveforms to the two-plain-streams pipeline."""
+    launch from two host threads; optionally several batches per token loop) produces bit-identical waveforms to the
+    two-plain-streams pipeline."""
     m, lc, fc, hc = _model()
     B, nb = 2, 5
     shared = _inputs(lc, fc, seed=0)
@@ -95,9 +96,12 @@ def test_tts_batches_cu_partition_equals_shared_streams():
 
     torch.manual_seed(0)
     ref = [w.clone() for w in m.tts_batches(batches(), llm_cu_slots=0)]
-    for k, loops, to_host in ((12, 1, True), (4, 2, False), (8, 3, True)):
+    # merge: consecutive batches decoded by ONE token loop (2 x 2 rows <= max_batch 4; 3 is clipped to what fits)
+    for k, loops, to_host, merge in ((12, 1, True, 1), (4, 2, False, 1), (8, 3, True, 1), (8, 2, True, 2), (8, 1, False, 3)):
         torch.manual_seed(0)
+        m.llm_merge = merge
         got = [w.cpu().clone() for w in m.tts_batches(batches(), to_host=to_host, llm_cu_slots=k, llm_loops=loops)]
+        m.llm_merge = 1
         assert len(got) == nb
         for a, b in zip(ref, got):
             assert a.shape == b.shape and torch.isfinite(b).all()

@@ -1,9 +1,11 @@
-"""Runs ONLY the roofline kernel of bench.py (decode gate/up skinny GEMM, B=8, all 24 layers' packed weights, 5 sweeps)
-so that rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes give its HBM traffic per launch."""
+"""Runs ONLY the roofline kernel of bench.py (decode gate/up skinny GEMM, B rows = argv[1], default 16 = two 8-utterance batches
+in one token loop; all 24 layers' packed weights, 5 sweeps) so that rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes give its HBM
+traffic per launch (tools/pmc_summarize.py turns the two counter CSVs into profiles/r01_roofline_pmc*.json)."""
 import sys, torch
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from cosyvoice_amd import ops
-H, I, B, L = 896, 4864, 8, 24
+H, I, L = 896, 4864, 24
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 dev = 'cuda'
 torch.manual_seed(0)
 xn = torch.zeros(16, H, device=dev, dtype=torch.bfloat16); xn[:B] = torch.randn(B, H, device=dev).to(torch.bfloat16)
