@@ -9,7 +9,7 @@ Kernels: the conformer layers, transformer blocks, implicit-GEMM convolutions (s
 CFM pack / update launches are the CosyVoice2 flow's; new here are ``cv_groupnorm_cl`` and ``cv_interp_linear_cl``.  The
 reference asserts batch 1, so every mask is all ones; the CFG pair runs as R = 2 rows."""
 import math
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 

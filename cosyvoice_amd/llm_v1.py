@@ -16,7 +16,7 @@ non-random-RAS mode."""
 import ctypes as C
 import math
 from types import SimpleNamespace
-from typing import Dict, Generator, List, Optional
+from typing import Generator, List, Optional
 
 import torch
 

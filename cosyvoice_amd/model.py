@@ -12,7 +12,6 @@ sequences, flow batched over B CFG pairs, HiFT batched over B mels.
 import threading
 import time
 import uuid
-from contextlib import nullcontext
 from typing import List, Optional
 
 import numpy as np

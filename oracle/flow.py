@@ -3,7 +3,6 @@
 Functional restatement over a flat state dict with the reference's key names.
 """
 import math
-from typing import Optional
 
 import torch
 import torch.nn.functional as F

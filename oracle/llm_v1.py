@@ -10,8 +10,6 @@ import torch
 import torch.nn.functional as F
 
 from . import flow as of
-from . import llm as ol
-from . import llm_phoneme as op
 
 
 def transformer_layer(sd, name, x, mask, pos_emb, heads):
