@@ -254,9 +254,16 @@ def measure_roofline(llm, lc, rows=UTT_PER_GPU):
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     # cycle through all 24 layers' weights (417 MB > 256 MB Infinity Cache) so every launch streams from HBM
+    split = llm.split_norm
+    npart = st["ssp"].shape[0]
+
     def launch(l):
-        ops.skinny_gemm(st["xn"], l["p_gu"], B, 2 * I, H, mode=2, out_act=st["h"], ldoa=I,
-                        norm=dict(x=st["x2"], gamma=l["g_post"], eps=lc.rms_eps))
+        if split:   # the form the decode step runs: 16-bit rows + the producer's partial sums of squares, 1/rms in the epilogue
+            ops.skinny_gemm(st["xb"], l["p_gu_g"], B, 2 * I, H, mode=2, out_act=st["h"], ldoa=I,
+                            split_in=dict(rs=st["ssp"], n=npart, eps=lc.rms_eps))
+        else:
+            ops.skinny_gemm(st["xn"], l["p_gu"], B, 2 * I, H, mode=2, out_act=st["h"], ldoa=I,
+                            norm=dict(x=st["x2"], gamma=l["g_post"], eps=lc.rms_eps))
 
     # the 24 launches are captured once and replayed: issued one by one from Python the host (~10 us per call) would be
     # the thing timed, not the 7 us kernel.  HIP events bracket the replays on the stream they run on.
@@ -268,20 +275,24 @@ def measure_roofline(llm, lc, rows=UTT_PER_GPU):
     ev1.record()
     torch.cuda.synchronize()
     dur = ev0.elapsed_time(ev1) * 1e-3 / (n_iter * len(lay))
-    alg = 2 * I * H * 2 + B * H * 4 + H * 4 + B * I * 2   # packed bf16 weights + fp32 residual rows + gamma + bf16 SwiGLU out
+    if split:
+        alg = 2 * I * H * 2 + B * H * 2 + npart * 16 * 4 + B * I * 2   # packed bf16 weights + bf16 rows + partial sums + bf16 SwiGLU out
+    else:
+        alg = 2 * I * H * 2 + B * H * 4 + H * 4 + B * I * 2   # packed bf16 weights + fp32 residual rows + gamma + bf16 SwiGLU out
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_roofline_pmc.json" if B <= 8 else "r01_roofline_pmc_b16.json")
+    pmc = os.path.join(ROOT, "profiles", ("r01_roofline_pmc_split_b%d.json" % B) if split else
+                       ("r01_roofline_pmc.json" if B <= 8 else "r01_roofline_pmc_b16.json"))
     if os.path.exists(pmc):  # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/roofline_pmc.py)
         try:
             traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
-    note = None
-    if B > UTT_PER_GPU:
-        note = (f"one launch streams the layer's gate/up weights for {B} sequences ({B // UTT_PER_GPU} batches share a token loop); "
-                "the 8-row form of the same kernel (one batch per loop, --llm-merge 1) runs 7.4 us = 0.295 of peak: the fused "
-                "RMSNorm prologue costs 2.0 us at 16 rows against 0.8 us at 8 (tools/roofline_time.py)")
-    return {"note": note, "bound": "hbm", "kernel": f"skinny_kernel<bf16,TPW=2,norm,TPR={32 if B <= 8 else 16},U=7> (decode gate/up + RMSNorm prologue + SwiGLU), {B} rows",
+    note = (f"one launch streams the layer's gate/up weights for {B} sequences ({max(1, B // UTT_PER_GPU)} batch(es) per token loop); the "
+            "post-attention RMSNorm is split over the o_proj launch (16-bit rows + per-workgroup partial sums of squares) and this "
+            "kernel's epilogue (1/rms; gamma folded into the packed weights), so no prologue sits in front of the MFMAs "
+            "(fused-prologue form: 7.4 us at 8 rows, 9.2-9.5 us at 16; tools/roofline_time.py)") if split else None
+    return {"note": note, "bound": "hbm", "kernel": (f"skinny_kernel<bf16,TPW=2,no prologue,U=7,RS> (decode gate/up, split RMSNorm: 1/rms in the epilogue, + SwiGLU), {B} rows" if split else
+                       f"skinny_kernel<bf16,TPW=2,norm,TPR={32 if B <= 8 else 16},U=7> (decode gate/up + RMSNorm prologue + SwiGLU), {B} rows"),
             "achieved": round(alg / dur / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg / dur / 8e12, 4),
             "traffic": traffic, "bytes_per_launch": alg, "avg_launch_us": round(dur * 1e6, 3)}
 

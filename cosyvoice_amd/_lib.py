@@ -91,6 +91,8 @@ class SkinnyParams(C.Structure):
         ("ngamma", _vp), ("neps", _f32),
         ("nx_out", _vp),
         ("max_wgs", _i32),
+        ("xb_out", _vp), ("ldxb", _i32), ("ss_part", _vp),
+        ("rs_part", _vp), ("n_rs_part", _i32), ("rs_eps", _f32),
     ]
 
 

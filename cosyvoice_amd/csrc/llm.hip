@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void pack_skinny_kernel(const uint16_t* W, uin
 // leaves the decode loop its 304 workgroups ran as two rounds (11.2 us instead of 7.3).  Gamma is staged through LDS and
 // read back just in time, the K = 896 slices use clamp-free immediate-offset loads (U = 7), and the kernel is bounded to
 // 168 VGPRs = three workgroups per CU: one round on 104 CUs, 16 stragglers on 96.
-template <int DT, int TPW, int NORM, int TPR, int U>
+template <int DT, int TPW, int NORM, int TPR, int U, bool RS = false>   // RS: consumer half of a split RMSNorm (rs_part)
 __global__ __launch_bounds__(256, ((TPW == 2 && TPR >= 32) ? 3 : 2)) void skinny_kernel(const cv_skinny_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float (*red)[TPW][64][4] = (float (*)[TPW][64][4])smem;           // [4][TPW][64][4]
@@ -90,6 +90,20 @@ __global__ __launch_bounds__(256, ((TPW == 2 && TPR >= 32) ? 3 : 2)) void skinny
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         resid[t][r] = p.out_f32[(int64_t)m * p.ldo + min((tile0 + t) * 16 + 4 * (lane >> 4) + r, p.N - 1)];
+  }
+  // consumer half of the split RMSNorm: the producer's per-workgroup partial sums of squares of this lane's row, fetched with
+  // the weights and summed in fixed order; 1/rms is applied in the epilogue
+  // (lane (m, g) takes partial rows g, g + 4, ...: one batch of 16 independent loads issued ahead of the weight stream and only
+  // consumed after the MFMAs; n_rs_part <= 64)
+  float rs_p[RS ? 16 : 1];
+  if constexpr (RS) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) rs_p[j] = 0.f;
+    if (wid == 0) {
+      const int m = min(lane & 15, p.M - 1), g4 = lane >> 4;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) rs_p[j] = p.rs_part[min(g4 + 4 * j, p.n_rs_part - 1) * 16 + m];
+    }
   }
 
   if constexpr (NORM != 0) {
@@ -216,10 +230,19 @@ __global__ __launch_bounds__(256, ((TPW == 2 && TPR >= 32) ? 3 : 2)) void skinny
     if constexpr (TPW == 2) {
       const int nb = tile0 * 16 + 4 * g;          // gate tile columns in packed order
       const int hcol = (tile0 >> 1) * 16 + 4 * g;  // output column
+      float rstd = 1.f;
+      if constexpr (RS) {
+        float rs_sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) rs_sum += (g + 4 * j < p.n_rs_part) ? rs_p[j] : 0.f;
+        rs_sum += __shfl_xor(rs_sum, 16, 64);
+        rs_sum += __shfl_xor(rs_sum, 32, 64);
+        rstd = rsqrtf(rs_sum / (float)p.K + p.rs_eps);
+      }
       float h[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float gt = v[0][r], up = v[1][r];
+        float gt = v[0][r] * rstd, up = v[1][r] * rstd;
         if (p.bias) { gt += p.bias[nb + r]; up += p.bias[nb + 16 + r]; }
         h[r] = act_silu(gt) * up;
       }
@@ -230,6 +253,7 @@ __global__ __launch_bounds__(256, ((TPW == 2 && TPR >= 32) ? 3 : 2)) void skinny
     }
     return;
   }
+  float ssq = 0.f;
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
     const int nb = (tile0 + t) * 16 + 4 * g;
@@ -239,10 +263,22 @@ __global__ __launch_bounds__(256, ((TPW == 2 && TPR >= 32) ? 3 : 2)) void skinny
       if (n >= p.N) continue;
       float o = v[t][r];
       if (p.bias && blockIdx.y == 0) o += p.bias[n];
-      if (p.mode == 1) p.out_f32[(int64_t)m * p.ldo + n] = resid[t][r] + o;
+      if (p.mode == 1) {
+        const float nx = resid[t][r] + o;
+        p.out_f32[(int64_t)m * p.ldo + n] = nx;
+        if (p.xb_out) {   // producer half of the split RMSNorm
+          ((uint16_t*)p.xb_out)[(int64_t)m * p.ldxb + n] = Elem16<DT>::from_f32(nx);
+          ssq += nx * nx;
+        }
+      }
       else if (p.mode == 3) ((uint16_t*)p.out_act)[(int64_t)m * p.ldoa + n] = Elem16<DT>::from_f32(fmaxf(o, 0.f));
       else p.out_f32[(int64_t)blockIdx.y * p.slab_stride + (int64_t)m * p.ldo + n] = o;
     }
+  }
+  if (p.mode == 1 && p.ss_part) {   // lanes m, m + 16, m + 32, m + 48 hold the four column groups of row m (all active together)
+    ssq += __shfl_xor(ssq, 16, 64);
+    ssq += __shfl_xor(ssq, 32, 64);
+    if (g == 0) p.ss_part[blockIdx.x * 16 + m] = ssq;
   }
 }
 
@@ -1137,9 +1173,16 @@ extern "C" int cv_skinny_gemm(const cv_skinny_params* pp, void* stream) {
   const int tpw = p.mode == 2 ? 2 : 1;
   if (p.mode == 2) {
     if (p.ksplit != 1 || (ntiles & 1) || !p.out_act || (p.ldoa & 3)) return CV_ERR_ARG;
+    if (p.rs_part) {
+      if (norm || p.n_rs_part <= 0 || p.n_rs_part > 64) return CV_ERR_ARG;
+      p.max_wgs = 0;
+    }
   } else if (p.mode == 3) {
     if (p.ksplit != 1 || !p.out_act || norm) return CV_ERR_ARG;
     p.max_wgs = 0;   // single-shot kernel only
+  } else if (p.mode == 1 && (p.xb_out || p.ss_part)) {
+    if (!p.out_f32 || p.ksplit != 1 || !p.xb_out || !p.ss_part || p.ldxb < p.N) return CV_ERR_ARG;
+    p.max_wgs = 0;
   } else {
     if (!p.out_f32) return CV_ERR_ARG;
     if (p.mode == 1 && p.ksplit != 1) return CV_ERR_ARG;
@@ -1147,6 +1190,7 @@ extern "C" int cv_skinny_gemm(const cv_skinny_params* pp, void* stream) {
   // k-steps one wave covers: the streaming kernel takes them as one batch of U fragment loads
   const int per_wave = ((((p.K >> 5) + p.ksplit - 1) / p.ksplit) + 3) >> 2;
   const int ngroups = ntiles / tpw;
+  if (p.mode == 2 && p.rs_part && per_wave > 8) return CV_ERR_UNSUPPORTED;   // split-norm consumer: K <= 1024 only
   if (per_wave > 16 || (tpw == 2 && per_wave > 8)) {
     if (norm) return CV_ERR_UNSUPPORTED;  // cannot happen: the prologue needs K <= 1024
     dim3 grid(ngroups, p.ksplit);
@@ -1184,7 +1228,10 @@ extern "C" int cv_skinny_gemm(const cv_skinny_params* pp, void* stream) {
     else { SK_TPR(TPW_, 5); }                  \
   } while (0)
   if (tpw == 2) {
-    if (nm == 0) { SK_LAUNCH(2, 0, 16, 8); } else { SK_NORM(2); }
+    if (nm == 0 && p.rs_part) {
+      if (exact7) { DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, 2, 0, 16, 7, true>), grid, dim3(256), lds, st, p)); }
+      else { DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, 2, 0, 16, 8, true>), grid, dim3(256), lds, st, p)); }
+    } else if (nm == 0) { SK_LAUNCH(2, 0, 16, 8); } else { SK_NORM(2); }
   } else if (nm == 0) {
     if (exact7) { SK_LAUNCH7(1, 0, 16); }
     else if (per_wave <= 8) { SK_LAUNCH(1, 0, 16, 8); } else if (per_wave <= 12) { SK_LAUNCH(1, 0, 16, 12); } else { SK_LAUNCH(1, 0, 16, 16); }

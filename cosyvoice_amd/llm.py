@@ -53,6 +53,7 @@ class Qwen2LM:
         # group prefetched (cv_skinny_params.max_wgs).  Measured slower than single-shot workgroups at three per CU on the
         # 104-CU share tts_batches gives the decode loop (tools/llm_kernel_bench.py), so it stays off.
         self.cu_budget = 0
+        self.split_norm = os.environ.get("CV_SPLIT_NORM", "1") != "0"   # decode step: post-attention RMSNorm split over o_proj / gate-up
         self.use_graph = True
         self._loaded = False
         self._graphs: Dict[int, ops.Graph] = {}
@@ -88,6 +89,9 @@ class Qwen2LM:
             lay["p_qkv"] = ops.pack_skinny(lay["wqkv"])
             lay["p_o"] = ops.pack_skinny(lay["wo"])
             lay["p_gu"] = ops.pack_skinny(w16(torch.cat([g, u], 0)), interleave=True)
+            # split-RMSNorm form of the decode step: gamma folded into the weights, 1/rms applied in the kernel's epilogue
+            gam = sd[lp + "post_attention_layernorm.weight"].float().unsqueeze(0)
+            lay["p_gu_g"] = ops.pack_skinny(w16(torch.cat([g * gam, u * gam], 0)), interleave=True)
             lay["p_down"] = ops.pack_skinny(lay["wdown"])
             self.layers.append(lay)
         self.g_final = f32(f"{P_}norm.weight")
@@ -122,7 +126,7 @@ class Qwen2LM:
         z = lambda *s, dtype=torch.float32: torch.zeros(*s, device=dev, dtype=dtype)
         self.Vpad = _round_up(cfg.out_vocab, 16)
         MB = self.max_batch
-        self.st = dict(x=z(16, H), x2=z(16, H), xn=z(16, H, dtype=dt), qkv=z(16, qkv_dim), q=z(16, cfg.q_dim, dtype=dt),
+        self.st = dict(x=z(16, H), x2=z(16, H), xn=z(16, H, dtype=dt), xb=z(16, H, dtype=dt), ssp=z((H + 15) // 16, 16), qkv=z(16, qkv_dim), q=z(16, cfg.q_dim, dtype=dt),
                        ao=z(16, cfg.q_dim, dtype=dt), h=z(16, I, dtype=dt), slabs=z(self.DOWN_KSPLIT, 16, H),
                        logits=z(16, self.Vpad), pos=z(16, dtype=torch.int32), step=z(16, dtype=torch.int32),
                        n_emitted=z(16, dtype=torch.int32), finished=z(16, dtype=torch.int32), min_len=z(16, dtype=torch.int32),
@@ -186,9 +190,18 @@ class Qwen2LM:
             ops.skinny_gemm(st["xn"], lay["p_qkv"], B, qkv_dim, H, bias=lay["bqkv"], out_f32=st["qkv"], ldo=qkv_dim, norm=nrm)
             ops.decode_attention(st["q"], self.kcache[li], self.vtcache[li], st["pos"], 1, st["ao"], B, cfg.num_heads,
                                  cfg.num_kv_heads, self.ctx_max, scale, qkv=st["qkv"], inv_freq=self.rope_table)
-            ops.skinny_gemm(st["ao"], lay["p_o"], B, H, cfg.q_dim, mode=1, out_f32=nxt, ldo=H)
-            ops.skinny_gemm(st["xn"], lay["p_gu"], B, 2 * I, H, mode=2, out_act=st["h"], ldoa=I,
-                            norm=dict(x=nxt, gamma=lay["g_post"], eps=cfg.rms_eps), max_wgs=mw)
+            if self.split_norm:
+                # post-attention RMSNorm split over the two launches: o_proj also leaves the updated rows as 16-bit and its
+                # workgroups' partial sums of squares; gate/up reads those rows straight into MFMA fragments (no prologue, no
+                # LDS image, no barrier) and applies 1/rms in its epilogue (gamma is folded into the packed weights)
+                ops.skinny_gemm(st["ao"], lay["p_o"], B, H, cfg.q_dim, mode=1, out_f32=nxt, ldo=H,
+                                split_out=dict(xb=st["xb"], ss=st["ssp"]))
+                ops.skinny_gemm(st["xb"], lay["p_gu_g"], B, 2 * I, H, mode=2, out_act=st["h"], ldoa=I,
+                                split_in=dict(rs=st["ssp"], n=st["ssp"].shape[0], eps=cfg.rms_eps))
+            else:
+                ops.skinny_gemm(st["ao"], lay["p_o"], B, H, cfg.q_dim, mode=1, out_f32=nxt, ldo=H)
+                ops.skinny_gemm(st["xn"], lay["p_gu"], B, 2 * I, H, mode=2, out_act=st["h"], ldoa=I,
+                                norm=dict(x=nxt, gamma=lay["g_post"], eps=cfg.rms_eps), max_wgs=mw)
             ops.skinny_gemm(st["h"], lay["p_down"], B, H, I, ksplit=KS, out_f32=st["slabs"], ldo=H, slab_stride=16 * H, max_wgs=mw)
             cur, nxt = nxt, cur
         ops.rmsnorm_reduce(cur, self.g_final, cfg.rms_eps, st["xn"], B, slabs=st["slabs"], nslab=KS, slab_stride=16 * H, ld_slab=H)
@@ -198,7 +211,8 @@ class Qwen2LM:
         if not self.use_graph:
             self._decode_step(B, use_forced, use_uniforms)
             return
-        key = (B, use_forced, use_uniforms, self.seed, self.cu_budget, self.top_p, self.top_k, self.fallback_mode, self.top_p2, self.top_k2)
+        key = (B, use_forced, use_uniforms, self.seed, self.cu_budget, self.top_p, self.top_k, self.fallback_mode, self.top_p2, self.top_k2,
+               self.split_norm)
         g = self._graphs.get(key)
         if g is None:
             g = ops.Graph().capture(lambda: self._decode_step(B, use_forced, use_uniforms))

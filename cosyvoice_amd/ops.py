@@ -349,7 +349,7 @@ def pack_skinny(W, interleave=False):
 
 
 def skinny_gemm(A, Wp, M, N, K, *, bias=None, ksplit=1, mode=0, out_f32=None, ldo=0, slab_stride=0, out_act=None, ldoa=0,
-                norm=None, max_wgs=0):
+                norm=None, max_wgs=0, split_out=None, split_in=None):
     """norm = dict(x=, gamma=, eps=, x_out=None, slabs=None, nslab=0, slab_stride=0, ld_slab=0): fused RMSNorm prologue
     (A is then unused; pass any 16-bit tensor for the dtype)."""
     _req_cuda(A, Wp, bias, out_f32, out_act)
@@ -368,6 +368,12 @@ def skinny_gemm(A, Wp, M, N, K, *, bias=None, ksplit=1, mode=0, out_f32=None, ld
         p.ngamma, p.neps = norm["gamma"].data_ptr(), norm["eps"]
         p.nx_out = L.ptr(norm.get("x_out"))
     p.max_wgs = max_wgs
+    if split_out is not None:   # producer of a split RMSNorm (mode 1): dict(xb=(16, N) 16-bit rows, ss=(N / 16, 16) fp32 partials)
+        _req_cuda(split_out["xb"], split_out["ss"])
+        p.xb_out, p.ldxb, p.ss_part = split_out["xb"].data_ptr(), split_out["xb"].stride(0), split_out["ss"].data_ptr()
+    if split_in is not None:    # consumer (mode 2): dict(rs=partials, n=number of partial rows, eps=)
+        _req_cuda(split_in["rs"])
+        p.rs_part, p.n_rs_part, p.rs_eps = split_in["rs"].data_ptr(), split_in["n"], split_in["eps"]
     _issue("cv_skinny_gemm", p)
 
 

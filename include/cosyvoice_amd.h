@@ -236,6 +236,13 @@ typedef struct cv_skinny_params {
   /* > 0: cap on the workgroups launched (x ksplit slices); each then walks several tile groups with the next group's
      weights prefetched.  Set to about 2 x the CUs the calling stream owns; 0 = one workgroup per tile group. */
   int32_t max_wgs;
+  /* RMSNorm split across two launches (the decode step's o_proj -> gate/up pair), so that the consumer needs no prologue:
+     producer (mode 1): xb_out != NULL also stores the updated rows as `dtype` (un-normalised) and ss_part[blockIdx.x][16] =
+     this workgroup's partial sum of squares of each row (fixed order: deterministic, no atomics);
+     consumer (mode 2, A = those 16-bit rows, gamma folded into the packed weights): rs_part != NULL scales gate and up by
+     rsqrt(sum_i rs_part[i][m] / K + rs_eps) in the epilogue. */
+  void* xb_out; int32_t ldxb; float* ss_part;
+  const float* rs_part; int32_t n_rs_part; float rs_eps;
 } cv_skinny_params;
 int cv_skinny_gemm(const cv_skinny_params* p, void* stream);
 /* CosyVoice-v1 TransformerLM cached decode step (TransformerEncoder.forward_chunk's att_cache, transformer/encoder.py:185-274):

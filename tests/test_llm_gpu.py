@@ -162,6 +162,64 @@ def test_rmsnorm_reduce_and_rope_decode_attention():
     assert (o_f[:B] - o_r[:B]).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [3, 8, 16])
+def test_split_rmsnorm_producer_consumer(dt, M):
+    """RMSNorm split over two skinny launches (the decode step's o_proj -> gate/up pair): the in-place-residual producer also
+    emits the updated rows as 16-bit and per-workgroup partial sums of squares; the SwiGLU consumer reads those rows without a
+    prologue and applies 1/rms in its epilogue, gamma folded into the packed weights.  Against torch, and against the
+    fused-prologue form of the same kernel."""
+    from cosyvoice_amd import ops
+    torch.manual_seed(M)
+    dev = "cuda"
+    H, Q, I, eps = 896, 896, 4864, 1e-6
+    ao = torch.zeros(16, Q, device=dev, dtype=dt)
+    ao[:M] = torch.randn(M, Q, device=dev).to(dt)
+    wo = (torch.randn(H, Q, device=dev) / Q ** 0.5).to(dt)
+    x0 = torch.randn(16, H, device=dev) * 3
+    x = x0.clone()
+    xb = torch.zeros(16, H, device=dev, dtype=dt)
+    ssp = torch.full((H // 16, 16), float("nan"), device=dev)
+    ops.skinny_gemm(ao, ops.pack_skinny(wo), M, H, Q, mode=1, out_f32=x, ldo=H, split_out=dict(xb=xb, ss=ssp))
+    x_ref = x0[:M] + ao[:M].float() @ wo.float().t()
+    assert (x[:M] - x_ref).abs().max().item() < 1e-3 * x_ref.abs().max().item()
+    assert torch.equal(xb[:M], x[:M].to(dt)) and torch.equal(x[M:], x0[M:])          # 16-bit copy of exactly what was stored
+    ss = ssp[:, :M].sum(0)
+    assert torch.isfinite(ss).all() and ((ss - (x[:M] ** 2).sum(1)).abs() / ss).max().item() < 1e-5
+    gamma = 1 + 0.1 * torch.randn(H, device=dev)
+    g = (torch.randn(I, H, device=dev) / H ** 0.5).to(dt)
+    u = (torch.randn(I, H, device=dev) / H ** 0.5).to(dt)
+    wp_g = ops.pack_skinny(torch.cat([g.float() * gamma, u.float() * gamma], 0).to(dt).contiguous(), interleave=True)
+    h = torch.zeros(16, I, device=dev, dtype=dt)
+    ops.skinny_gemm(xb, wp_g, M, 2 * I, H, mode=2, out_act=h, ldoa=I, split_in=dict(rs=ssp, n=H // 16, eps=eps))
+    xn = x[:M] * torch.rsqrt((x[:M] ** 2).mean(1, keepdim=True) + eps) * gamma
+    ref = torch.nn.functional.silu(xn @ g.float().t()) * (xn @ u.float().t())
+    tol = 4e-2 if dt == torch.bfloat16 else 5e-3
+    scale = max(1.0, ref.abs().max().item())
+    assert (h[:M].float() - ref).abs().max().item() < tol * scale
+    # the fused-prologue form of the same product
+    h2 = torch.zeros_like(h)
+    ops.skinny_gemm(xb, ops.pack_skinny(torch.cat([g, u], 0).contiguous(), interleave=True), M, 2 * I, H, mode=2, out_act=h2, ldoa=I,
+                    norm=dict(x=x, gamma=gamma, eps=eps))
+    assert (h2[:M].float() - h[:M].float()).abs().max().item() < tol * scale
+    assert (h[M:] == 0).all()
+
+
+def test_decode_step_split_norm_equals_fused_prologue(golden_dir):
+    """Qwen2LM decode loop with the post-attention RMSNorm split over o_proj / gate-up (default) against the fused-prologue
+    form: both within the golden tolerance, and close to each other."""
+    from cosyvoice_amd.llm import Qwen2LM
+    cfg = LlmConfig.tiny()
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, "llm_tiny.npz")).items()}
+    lm = Qwen2LM(cfg, dtype=torch.float16, max_batch=4, ctx_max=256, max_out=256).load_state_dict(llm_state_dict(cfg))
+    out = {}
+    for split in (True, False):
+        lm.split_norm = split
+        out[split] = lm.forced_logits(g["text"], g["prompt_text"], g["prompt_speech"], g["forced"].tolist()).cpu()
+        assert (out[split] - g["logps"]).abs().max().item() < 2e-2
+    assert (out[True] - out[False]).abs().max().item() < 2e-2 and not torch.equal(out[True], out[False])
+
+
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 1.5e-1), (torch.float16, 2e-2)])
 def test_teacher_forced_logp_vs_golden(golden_dir, dt, tol):
     from cosyvoice_amd.llm import Qwen2LM

@@ -12,7 +12,12 @@ xn = torch.zeros(16, H, device=dev, dtype=torch.bfloat16); xn[:B] = torch.randn(
 x = torch.randn(16, H, device=dev); gam = torch.ones(H, device=dev)
 h = torch.zeros(16, I, device=dev, dtype=torch.bfloat16)
 packs = [ops.pack_skinny((torch.randn(2 * I, H, device=dev) / H ** 0.5).to(torch.bfloat16), interleave=True) for _ in range(L)]
+split = len(sys.argv) > 2 and sys.argv[2] == "split"      # the decode step's form: 16-bit rows + partial sums, 1/rms in the epilogue
+ssp = torch.rand(56, 16, device=dev)
 for _ in range(5):
     for p in packs:
-        ops.skinny_gemm(xn, p, B, 2 * I, H, mode=2, out_act=h, ldoa=I, norm=dict(x=x, gamma=gam, eps=1e-6))
+        if split:
+            ops.skinny_gemm(xn, p, B, 2 * I, H, mode=2, out_act=h, ldoa=I, split_in=dict(rs=ssp, n=56, eps=1e-6))
+        else:
+            ops.skinny_gemm(xn, p, B, 2 * I, H, mode=2, out_act=h, ldoa=I, norm=dict(x=x, gamma=gam, eps=1e-6))
 torch.cuda.synchronize()

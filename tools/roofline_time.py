@@ -31,3 +31,17 @@ for B in (8, 16):
         g.launch()
     e1.record(); torch.cuda.synchronize()
     print(f"rows {B}, no norm prologue: {e0.elapsed_time(e1) * 1e3 / (50 * L):.2f} us per launch", flush=True)
+
+# split-RMSNorm form (what the decode step runs): 16-bit rows + per-workgroup partial sums from the producer, 1/rms in the epilogue
+ssp = torch.rand(56, 16, device=dev)
+for B in (8, 16):
+    g = ops.Graph().capture(lambda: [ops.skinny_gemm(xn, p, B, 2 * I, H, mode=2, out_act=h, ldoa=I, split_in=dict(rs=ssp, n=56, eps=1e-6)) for p in packs])
+    g.launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        g.launch()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (50 * L)
+    alg = 2 * I * H * 2 + B * H * 2 + 56 * 16 * 4 + B * I * 2
+    print(f"rows {B}, split norm: {us:.2f} us per launch, {alg / us / 1e6:.2f} TB/s = {alg / us / 8e6:.3f} of 8 TB/s", flush=True)
