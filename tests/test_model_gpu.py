@@ -158,3 +158,34 @@ def test_v1_wiring_orchestrator_chunk_schedule(golden_dir):
     # speed change (non-stream only, model.py:165-168): linear interpolation of the mel
     fast = [o["tts_speech"] for o in m.vc(*args, stream=False, speed=2.0)]
     assert fast[0].shape[1] == int(g["full_samples"][0]) // 2
+
+
+@pytest.mark.gpu
+def test_tts_batches_merged_loops_free_running():
+    """Two batches per token loop without teacher forcing: every utterance ends at its own step, the merged job's tokens are
+    handed back per batch, flow + HiFT run per batch over ragged lengths."""
+    m, lc, fc, hc = _model()
+    B, nb = 2, 3
+    shared = _inputs(lc, fc, seed=0)
+    batches = []
+    for i in range(nb):
+        ins = [_inputs(lc, fc, seed=20 * i + s, n_text=3 + s + i) for s in range(B)]
+        batches.append(dict(texts=[x["text"].cuda() for x in ins], prompt_texts=[shared["prompt_text"].cuda()] * B,
+                            llm_prompt_speech_tokens=[shared["llm_prompt_speech_token"].cuda()] * B,
+                            flow_prompt_speech_tokens=shared["flow_prompt_speech_token"].cuda().expand(B, -1),
+                            prompt_speech_feats=shared["prompt_speech_feat"].cuda().expand(B, -1, -1),
+                            flow_embeddings=shared["flow_embedding"].cuda().expand(B, -1)))
+    m.llm_merge = 2
+    try:
+        outs = list(m.tts_batches(batches, to_host=True, llm_cu_slots=8, llm_loops=2))
+    finally:
+        m.llm_merge = 1
+    assert len(outs) == nb
+    for i, wavs in enumerate(outs):
+        wavs = wavs if isinstance(wavs, list) else list(wavs)
+        assert len(wavs) == B
+        for s, w in enumerate(wavs):
+            n_text = 3 + s + i
+            n = w.numel() // (2 * hc.total_upsample)
+            assert w.numel() == n * 2 * hc.total_upsample and 2 * n_text <= n <= 20 * n_text
+            assert torch.isfinite(w).all() and w.abs().max() <= 0.99 + 1e-6
