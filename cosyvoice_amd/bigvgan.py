@@ -151,6 +151,7 @@ class BigVGAN:
         ws = self._ws.get((B, N))
         if ws is not None:
             return ws
+        ops.bound_cache(self._ws, (B, N))
         cfg, dt, dev = self.cfg, self.dtype, self.device
         z = lambda *s, dtype=torch.float32: torch.zeros(*s, device=dev, dtype=dtype)   # zero: padded channels stay finite
         ch = 4 if dt == torch.float32 else 8

@@ -518,6 +518,11 @@ class CausalMaskedDiffWithXvec:
 
     def _buffers(self, B, N, D):
         key = (B, N, D)
+        # every per-shape cache of the flow hangs off this one (encoder / estimator workspaces, position tables, the captured
+        # Euler loops that hold their addresses): bounded together
+        enc, est = self.encoder, self.decoder.estimator
+        ops.bound_cache(self._bufs, key, enc._ws, enc._pos, est._ws, self.decoder._graphs, getattr(self.decoder, "_klen2", {}),
+                        cap=getattr(self, "shape_cache_cap", None))
         if key not in self._bufs:
             dev = self.device
             Dp = _round_up(D, 8)

@@ -175,6 +175,8 @@ class MaskedDiffWithXvec:
 
     def _buffers(self, N, Tm, D):
         key = (N, Tm, D)
+        enc, est = self.encoder, self.decoder.estimator      # all per-shape caches of the flow are bounded together
+        ops.bound_cache(self._bufs, key, enc._ws, enc._pos, est._ws, self.decoder._graphs, cap=getattr(self, "shape_cache_cap", None))
         if key not in self._bufs:
             dev, O = self.device, self.cfg.output_size
             e = lambda *s, dtype=torch.float32: torch.empty(*s, device=dev, dtype=dtype)

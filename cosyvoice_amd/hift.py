@@ -129,6 +129,7 @@ class HiFTGenerator:
         ws = self._ws.get(key)
         if ws is not None:
             return ws
+        ops.bound_cache(self._ws, key)
         cfg, dt, dev = self.cfg, self.dtype, self.device
         e = lambda *shape, dtype=torch.float32: torch.empty(*shape, device=dev, dtype=dtype)
         ws = {}

@@ -263,6 +263,7 @@ class Qwen2LM:
 
     def _prefill_workspace(self, B, Lp):
         key = (B, Lp)
+        ops.bound_cache(self._prefill_ws, key)
         if key not in self._prefill_ws:
             cfg, dt, dev = self.cfg, self.dtype, self.device
             rows = B * Lp

@@ -149,6 +149,7 @@ class Qwen2LM_Phoneme_Src2:
 
     def _workspace(self, P_, L):
         key = (P_, L)
+        ops.bound_cache(self._ws, key, self.encoder._ws, self.encoder._pos)
         if key not in self._ws:
             dt, dev, H = self.dtype, self.device, self.lcfg.hidden_size
             W = self.pcfg.src_heads * 64

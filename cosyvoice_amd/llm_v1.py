@@ -224,6 +224,7 @@ class TransformerLM:
         c, dt, dev = self.cfg, self.dtype, self.device
         ids = torch.cat([prompt_text.reshape(-1), text.reshape(-1)]).to(dev, torch.int32)
         Lt = ids.numel()
+        ops.bound_cache(self.text_encoder._ws, (1, Lt), self.text_encoder._pos)      # one workspace / position table per text length
         ews = self.text_encoder._workspace(1, Lt)
         ops.embedding(self.text_table, ids, ews["x_in"].view(Lt, -1))
         enc = self.text_encoder.forward(ews, 1, Lt).view(Lt, c.enc_dim)

@@ -36,6 +36,24 @@ class f32_products:
         _tls.f32_mode = self.prev
 
 
+SHAPE_CACHE_CAP = 64
+
+
+def bound_cache(cache: dict, key, *dependents, cap=None):
+    """Workspaces, projected position tables and captured graphs are cached per request shape; a service sees an open-ended set
+    of lengths.  Call before inserting ``key``: when ``cache`` already holds ``cap`` other shapes, the device is drained and
+    ``cache`` plus every dict in ``dependents`` (caches holding pointers into it: captured graphs, buffers) are emptied — a rare
+    full flush instead of unbounded growth.  Returns True when a flush happened."""
+    cap = SHAPE_CACHE_CAP if cap is None else cap
+    if key in cache or len(cache) < cap:
+        return False
+    torch.cuda.synchronize()
+    cache.clear()
+    for d in dependents:
+        d.clear()
+    return True
+
+
 class Recorder:
     """Collects the parameter blocks of cv_gemm / cv_layernorm / cv_attention calls instead of launching them, so a fixed
     launch sequence (the v1 LM's cached decode step) is built once and re-issued with a few patched fields per step: the

@@ -174,3 +174,32 @@ def test_ragged_batch_equals_single_utterances():
         for b, (p, n) in enumerate(shapes):
             assert together[b].shape == alone[b].shape == (80, 2 * n)
             assert (together[b] - alone[b]).abs().max().item() < 2e-4, (chunk, b, (together[b] - alone[b]).abs().max().item())
+
+
+@pytest.mark.gpu
+def test_shape_caches_are_bounded():
+    """A service sees an open-ended set of request lengths: the per-shape caches (buffers, encoder / estimator workspaces,
+    position tables, captured Euler loops) are flushed together once ``shape_cache_cap`` shapes are held, and results after a
+    flush equal those of a fresh model."""
+    from cosyvoice_amd.config import FlowConfig
+    from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
+    from cosyvoice_amd.weights import flow_state_dict
+    fc = FlowConfig.tiny()
+    sd = flow_state_dict(fc)
+    m = CausalMaskedDiffWithXvec(fc, dtype=torch.float16).load_state_dict(sd)
+    m.decoder.use_graph = True
+    m.shape_cache_cap = 2
+    g = torch.Generator().manual_seed(0)
+    ptok = torch.randint(0, fc.vocab_size, (1, 6), generator=g, dtype=torch.int32)
+    pfeat = torch.clamp(torch.randn(1, 12, 80, generator=g) * 2 - 6, -11.5, 2.0)
+    emb = torch.randn(1, fc.spk_embed_dim, generator=g)
+    toks = {n: torch.randint(0, fc.vocab_size, (1, n), generator=g, dtype=torch.int32) for n in (5, 7, 9, 11, 5, 7)}
+    outs = {}
+    for n, tok in toks.items():
+        for rep in range(2):      # second call of a shape replays the captured loop
+            mel = m.inference_batch(tok, ptok, pfeat, emb).clone()
+        outs[n] = mel
+        assert len(m._bufs) <= 2 and len(m.encoder._ws) <= 2 and len(m.decoder.estimator._ws) <= 2 and len(m.decoder._graphs) <= 2
+    fresh = CausalMaskedDiffWithXvec(fc, dtype=torch.float16).load_state_dict(sd)
+    for n, tok in toks.items():
+        assert torch.equal(fresh.inference_batch(tok, ptok, pfeat, emb), outs[n])
