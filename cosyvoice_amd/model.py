@@ -57,6 +57,12 @@ class CosyVoice2Model:
         self.llm_loops = 2      # tts_batches: concurrent decode loops (each its own batch / KV caches) on those CUs
         self.llm_merge = 1      # tts_batches: consecutive batches decoded by ONE token loop (rows <= llm.max_batch)
         self.lock = threading.Lock()
+        # The reference's modules are re-entrant (every call builds its own activations / KV cache); here the stage objects own
+        # their KV caches, workspaces and captured graphs, so concurrent requests on ONE model object take turns per stage: a
+        # request holds llm_lock for its decode loop and flow_lock for each token2wav call (throughput across requests comes
+        # from tts_batch / tts_batches, which batch utterances instead of interleaving them).
+        self.llm_lock = threading.Lock()
+        self.flow_lock = threading.Lock()
         self.tts_speech_token_dict = {}
         self.llm_end_dict = {}
         self.hift_cache_dict = {}
@@ -85,7 +91,7 @@ class CosyVoice2Model:
         else:
             text_a, text_len = text.to(dev), torch.tensor([text.shape[1]], dtype=torch.int32)
             ptext_a, ptext_len = prompt_text.to(dev), torch.tensor([prompt_text.shape[1]], dtype=torch.int32)
-        with self.llm_context:
+        with self.llm_lock, self.llm_context:
             for i in self.llm.inference(text=text_a,
                                         text_len=text_len,
                                         prompt_text=ptext_a,
@@ -96,7 +102,12 @@ class CosyVoice2Model:
                 self.tts_speech_token_dict[uuid_].append(i)
         self.llm_end_dict[uuid_] = True
 
-    def token2wav(self, token, prompt_token, prompt_feat, embedding, uuid_, token_offset, finalize=False, speed=1.0):
+    def token2wav(self, *args, **kwargs):
+        """Reference signature (model.py:334 / :130 for the v1 wiring); one call at a time per model object (flow_lock)."""
+        with self.flow_lock:
+            return self._token2wav(*args, **kwargs)
+
+    def _token2wav(self, token, prompt_token, prompt_feat, embedding, uuid_, token_offset, finalize=False, speed=1.0):
         # model.py:334-366
         tts_mel, _ = self.flow.inference(token=token.to(self.device),
                                          token_len=torch.tensor([token.shape[1]], dtype=torch.int32),
@@ -380,7 +391,7 @@ class CosyVoiceModel(CosyVoice2Model):
         self.mel_overlap_dict = {}
         self.flow_cache_dict = {}
 
-    def token2wav(self, token, prompt_token=torch.zeros(1, 0, dtype=torch.int32), prompt_feat=torch.zeros(1, 0, 80),
+    def _token2wav(self, token, prompt_token=torch.zeros(1, 0, dtype=torch.int32), prompt_feat=torch.zeros(1, 0, 80),
                   embedding=torch.zeros(0, 512), uuid_="0", finalize=False, speed=1.0):
         # model.py:130-172
         n = lambda t: torch.tensor([t.shape[1]], dtype=torch.int32)

@@ -189,3 +189,32 @@ def test_tts_batches_merged_loops_free_running():
             n = w.numel() // (2 * hc.total_upsample)
             assert w.numel() == n * 2 * hc.total_upsample and 2 * n_text <= n <= 20 * n_text
             assert torch.isfinite(w).all() and w.abs().max() <= 0.99 + 1e-6
+
+
+@pytest.mark.gpu
+def test_concurrent_tts_requests_take_turns():
+    """Two request threads on ONE model object (the reference's server runtimes do this): the stage objects own their KV caches /
+    workspaces, so requests take turns per stage (llm_lock, flow_lock) and each gets exactly what it gets when run alone
+    (the sampler is seeded per request, so the token count — hence the waveform length — is reproducible)."""
+    import threading
+    m, lc, fc, hc = _model()
+    reqs = [_inputs(lc, fc, seed=s, n_text=n) for s, n in ((1, 4), (2, 7), (3, 5))]
+    alone = [sum(o["tts_speech"].shape[1] for o in m.tts(**r, stream=False)) for r in reqs]
+    got, errs = [None] * len(reqs), []
+
+    def run(i):
+        try:
+            outs = list(m.tts(**reqs[i], stream=False))
+            assert all(torch.isfinite(o["tts_speech"]).all() for o in outs)
+            got[i] = sum(o["tts_speech"].shape[1] for o in outs)
+        except Exception as e:      # surfaced in the main thread
+            errs.append(e)
+
+    ths = [threading.Thread(target=run, args=(i,)) for i in range(len(reqs))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    assert got == alone
+    assert not m.tts_speech_token_dict and not m.llm_end_dict and not m.hift_cache_dict
