@@ -6,14 +6,14 @@
 //   * the S^T accumulator registers are, after exp and 16-bit packing, directly the B operand of O^T += V^T . P^T
 //     (k-slot (g,j<4) = key 16*kt0+4g+j, (g,j>=4) = key 16*kt1+4g+j-4): no LDS round trip for P;
 //   * V arrives pre-transposed (V^T [d][key], written by the QKV GEMM epilogue), so its A fragment is two 8-byte
-//     LDS reads per lane from a [64 d][144 B] image (pitch 144 B: conflict-free for ds_read_b64).
+//     LDS reads per lane from a [64 d][128 B] image with XOR-swizzled 16-byte chunk slots.
 // K / V^T tiles (64 keys) are staged through LDS, double-buffered with register prefetch (one barrier per tile).
 #include "cv_device.h"
 
 namespace {
 
 constexpr int KT_BYTES = 8192;        // K tile: 64 keys x 128 B, row-major with XOR-swizzled 16-byte chunk slots
-constexpr int VT_PITCH = 144;         // bytes per d-row of the V^T tile (128 data + 16 pad)
+constexpr int VT_PITCH = 128;         // bytes per d-row of the V^T tile; 16-byte chunk slots XOR-swizzled by (row >> 1) & 7
 constexpr int VT_BYTES = 64 * VT_PITCH;
 constexpr int STAGE_BYTES = KT_BYTES + VT_BYTES;
 constexpr float NEG_BIG = -1e30f;
@@ -108,7 +108,10 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const cv_attn_params p) {
         const uint32_t m_hi = (2 * e + 1 < nvalid) ? 0xFFFF0000u : 0u;
         u[e] &= (m_lo | m_hi);
       }
-      *(uint4*)(sv + r * VT_PITCH + dc * 16) = make_uint4(u[0], u[1], u[2], u[3]);
+      // V^T image: 128-byte rows, chunk slot XOR (r >> 1) & 7 — 8 lanes fill one row (32 banks), the next 8 the other 32;
+      // a fragment read (16 consecutive rows, one chunk) hits 8 distinct slots per bank half.  The padded 144-byte pitch it
+      // replaces left 30 % of the kernel's LDS cycles as bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
+      *(uint4*)(sv + r * VT_PITCH + ((dc ^ ((r >> 1) & 7)) << 4)) = make_uint4(u[0], u[1], u[2], u[3]);
     }
   };
 
@@ -233,10 +236,12 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const cv_attn_params p) {
     // ---- O^T += V^T . P^T
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      const char* vrow = sv + (dt * 16 + lq) * VT_PITCH + lg * 16;
+      const int vr = dt * 16 + lq;
+      const char* vrow = sv + vr * VT_PITCH;
+      const int vsw = (vr >> 1) & 7;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const uint4 vf = *(const uint4*)(vrow + s2 * 64);
+        const uint4 vf = *(const uint4*)(vrow + (((lg + 4 * s2) ^ vsw) << 4));
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = mfma_block<DT>(vf, pf[qt][s2], oacc[dt][qt]);
       }
