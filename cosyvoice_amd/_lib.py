@@ -96,6 +96,22 @@ class SkinnyParams(C.Structure):
     ]
 
 
+class TBlockParams(C.Structure):
+    _fields_ = [
+        ("dtype", _i32), ("R", _i32), ("T", _i32), ("C", _i32), ("inner", _i32), ("ff", _i32),
+        ("x", _vp), ("ldx", _i32), ("eps", _f32),
+        ("g1", _vp), ("b1n", _vp), ("wqkv_p", _vp),
+        ("qk", _vp), ("ldqk", _i32),
+        ("vt", _vp), ("vt_ld", _i32),
+        ("ao", _vp), ("ldao", _i32),
+        ("wo_p", _vp), ("bo", _vp),
+        ("g3", _vp), ("b3n", _vp),
+        ("w1_p", _vp), ("bf1", _vp),
+        ("w2_p", _vp), ("bf2", _vp),
+        ("out_act", _vp), ("ldoa", _i32),
+    ]
+
+
 class SampleParams(C.Structure):
     _fields_ = [
         ("logits", _vp), ("ldl", _i32), ("V", _i32), ("B", _i32),
@@ -126,7 +142,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.cv_arch.restype = C.c_char_p
         for name, st in (("gemm", GemmParams), ("norm", NormParams), ("attn", AttnParams), ("skinny", SkinnyParams),
-                         ("sample", SampleParams), ("groupnorm", GroupNormParams)):
+                         ("sample", SampleParams), ("groupnorm", GroupNormParams), ("tblock", TBlockParams)):
             fn = getattr(_lib, f"cv_sizeof_{name}_params")
             if fn() != C.sizeof(st):
                 raise RuntimeError(f"ABI mismatch for cv_{name}_params: C {fn()} vs ctypes {C.sizeof(st)}")
@@ -141,7 +157,8 @@ EXPORTS = ["cv_version", "cv_arch", "cv_gemm", "cv_layernorm", "cv_attention",
            "cv_stream_destroy", "cv_skinny_gemm", "cv_pack_skinny", "cv_rmsnorm_reduce", "cv_rope_append",
            "cv_decode_attention", "cv_sample_ras", "cv_sizeof_skinny_params", "cv_sizeof_sample_params", "cv_anti_alias_act", "cv_anti_alias_act_cl",
            "cv_stft_magnitude", "cv_log_clamp_channels_first", "cv_groupnorm_cl", "cv_groupnorm_workspace_floats",
-           "cv_interp_linear_cl", "cv_sizeof_groupnorm_params", "cv_relpos_append"]
+           "cv_interp_linear_cl", "cv_sizeof_groupnorm_params", "cv_relpos_append", "cv_sizeof_tblock_params", "cv_tblock_head",
+           "cv_tblock_tail"]
 
 TORCH_DT = {torch.float32: CV_F32, torch.bfloat16: CV_BF16, torch.float16: CV_F16}
 DT_TORCH = {v: k for k, v in TORCH_DT.items()}

@@ -13,6 +13,7 @@ Beyond the reference (which is batch-1 only, flow.py:277): ``inference_batch`` r
 one pass (the CFG pair of every utterance is batched: 2B sequences per estimator call).
 """
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -232,14 +233,28 @@ class ConditionalDecoder:
                     g2=P.f32(f"{name}.block2.block.{n}.weight"), be2=P.f32(f"{name}.block2.block.{n}.bias"),
                     wr=P.conv(f"{name}.res_conv.weight"), br=P.f32(f"{name}.res_conv.bias"))
 
+    @property
+    def fused(self):
+        """The row-block kernels (cv_tblock_head / cv_tblock_tail) cover the widths of the reference wiring (256 channels, 8 x 64
+        heads, 4 x FFN: cosyvoice2 yaml :68-78) in 16-bit operands; anything else keeps the cv_gemm / cv_layernorm launches.
+        CV_FLOW_FUSED=0 forces the unfused launches (A/B measurements, cross-check tests)."""
+        cfg = self.cfg
+        return (os.environ.get("CV_FLOW_FUSED", "1") != "0" and self.dtype in (torch.float16, torch.bfloat16)
+                and cfg.est_channels == 256 and cfg.est_inner == 512 and cfg.est_head_dim == 64 and cfg.est_ff_mult == 4)
+
     def _load_tblock(self, P, sd, name):
         wqk = torch.cat([sd[f"{name}.attn1.to_q.weight"].float(), sd[f"{name}.attn1.to_k.weight"].float()], 0)
-        return dict(g1=P.f32(f"{name}.norm1.weight"), b1=P.f32(f"{name}.norm1.bias"),
-                    wqk=wqk.to(device=self.device, dtype=self.dtype).contiguous(), wv=P.w(f"{name}.attn1.to_v.weight"),
-                    wo=P.w(f"{name}.attn1.to_out.0.weight"), bo=P.f32(f"{name}.attn1.to_out.0.bias"),
-                    g3=P.f32(f"{name}.norm3.weight"), b3=P.f32(f"{name}.norm3.bias"),
-                    wf1=P.w(f"{name}.ff.net.0.proj.weight"), bf1=P.f32(f"{name}.ff.net.0.proj.bias"),
-                    wf2=P.w(f"{name}.ff.net.2.weight"), bf2=P.f32(f"{name}.ff.net.2.bias"))
+        tb = dict(g1=P.f32(f"{name}.norm1.weight"), b1=P.f32(f"{name}.norm1.bias"),
+                  wqk=wqk.to(device=self.device, dtype=self.dtype).contiguous(), wv=P.w(f"{name}.attn1.to_v.weight"),
+                  wo=P.w(f"{name}.attn1.to_out.0.weight"), bo=P.f32(f"{name}.attn1.to_out.0.bias"),
+                  g3=P.f32(f"{name}.norm3.weight"), b3=P.f32(f"{name}.norm3.bias"),
+                  wf1=P.w(f"{name}.ff.net.0.proj.weight"), bf1=P.f32(f"{name}.ff.net.0.proj.bias"),
+                  wf2=P.w(f"{name}.ff.net.2.weight"), bf2=P.f32(f"{name}.ff.net.2.bias"))
+        if self.fused:
+            # fragment-ordered copies for the row-block kernels: every wave-load of a weight fragment is 1 KiB contiguous
+            tb.update(wqkv_p=ops.pack_skinny(torch.cat([tb["wqk"], tb["wv"]], 0).contiguous()), wo_p=ops.pack_skinny(tb["wo"]),
+                      wf1_p=ops.pack_skinny(tb["wf1"]), wf2_p=ops.pack_skinny(tb["wf2"]))
+        return tb
 
     def _load_time(self, P, sd, prefix, names):
         """time-embedding path (input independent): TimestepEmbedding + every resnet's Mish->Linear, stacked"""
@@ -328,6 +343,21 @@ class ConditionalDecoder:
         C, inner, ff, H = cfg.est_channels, cfg.est_inner, cfg.est_channels * cfg.est_ff_mult, cfg.est_heads
         T, Tp = ws["T"], ws["Tp"]
         rows = R * T
+        if "wqkv_p" in tb and self.fused:
+            # three launches: LN + [Q | K | V^T]  ->  flash attention  ->  to_out + residual + LN + FFN + residual
+            p = ops.tblock_params(ws["x32"], R, T, 1e-5, self.dtype)
+            p.g1, p.b1n, p.wqkv_p = tb["g1"].data_ptr(), tb["b1"].data_ptr(), tb["wqkv_p"].data_ptr()
+            p.qk, p.ldqk, p.vt, p.vt_ld = ws["qk"].data_ptr(), 2 * inner, ws["vt"].data_ptr(), Tp
+            ops.tblock_head(p)
+            ops.attention(ws["qk"], ws["qk"][:, :, inner:], ws["vt"], ws["ao"], B=R, H=H, Hkv=H, Tq=T, Tk=T, scale=cfg.est_head_dim ** -0.5,
+                          q_bs=T * 2 * inner, ldq=2 * inner, k_bs=T * 2 * inner, ldk=2 * inner, vt_ld=Tp, o_bs=T * inner, ldo=inner, klen=klen)
+            p.ao, p.ldao, p.wo_p, p.bo = ws["ao"].data_ptr(), inner, tb["wo_p"].data_ptr(), tb["bo"].data_ptr()
+            p.g3, p.b3n = tb["g3"].data_ptr(), tb["b3"].data_ptr()
+            p.w1_p, p.bf1, p.w2_p, p.bf2 = tb["wf1_p"].data_ptr(), tb["bf1"].data_ptr(), tb["wf2_p"].data_ptr(), tb["bf2"].data_ptr()
+            if out_act is not None:
+                p.out_act, p.ldoa = out_act.data_ptr(), ldoa
+            ops.tblock_tail(p)
+            return
         x2 = ws["x32"].view(rows, C)
         ops.layernorm(x2, tb["g1"], tb["b1"], 1e-5, out_act=ws["xn"].view(rows, C))
         # Q | K row-major in one GEMM; V^T directly as the swapped product Wv . xn^T (rows = head*64 + d, keys contiguous)

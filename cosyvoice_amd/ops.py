@@ -178,6 +178,25 @@ def attention(q, k, vt, out, *, H, Hkv, Tq, Tk, scale, q_bs, ldq, k_bs, ldk, vt_
     _issue("cv_attention", p)
 
 
+# ----------------------------------------------------------------------------- fused transformer block (CFM estimator)
+def tblock_params(x, R, T, eps, dtype):
+    """x (R, T, 256) fp32 residual stream -> parameter block shared by tblock_head / tblock_tail (fill the stage fields)."""
+    _req_cuda(x)
+    p = L.TBlockParams()
+    p.dtype, p.R, p.T = L.TORCH_DT[dtype], R, T
+    p.C, p.inner, p.ff = 256, 512, 1024
+    p.x, p.ldx, p.eps = x.data_ptr(), x.stride(-2), eps
+    return p
+
+
+def tblock_head(p):
+    _issue("cv_tblock_head", p)
+
+
+def tblock_tail(p):
+    _issue("cv_tblock_tail", p)
+
+
 # ----------------------------------------------------------------------------- layout / HiFT helpers
 def to_channels_last(x, out):
     """x (B,C,T) fp32 -> out (B,T,ld) any dtype, zero-filled pad columns."""

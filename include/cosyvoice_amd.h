@@ -135,6 +135,41 @@ int cv_attention(const cv_attn_params* p, void* stream);
 
 
 /* ------------------------------------------------------------------------------------------
+ * cv_tblock_head / cv_tblock_tail — the CFM estimator's BasicTransformerBlock
+ * (flow/components/transformer.py:243-316 forward, :159-236 ctor, FeedForward :83-134; diffusers 0.27.2 Attention / GELU
+ * semantics as SURVEY.md §8c states them) as two row-block kernels around the cv_attention launch:
+ *   head: xn = LayerNorm(norm1)(x);  qk[row] = [xn Wq^T | xn Wk^T] (row-major, ldqk);  vt = (xn Wv^T)^T per head
+ *   tail: x1 = x + ao Wo^T + bo (skipped when ao == NULL: x1 = x);  xn = LayerNorm(norm3)(x1);
+ *         x  = x1 + gelu_erf(xn W1^T + bf1) W2^T + bf2   (in place);  out_act = T(x) when given
+ * x [R][T][ldx] fp32 residual stream (C = 256 channels), 64 rows of one sequence per workgroup; weights pre-packed
+ * by cv_pack_skinny (MFMA fragment order) and streamed L2 -> VGPR once per 64 rows; the 1024-wide GELU intermediate
+ * and the LayerNorm outputs never leave the CU.  Fixed widths C = 256, inner = 8 heads x 64 = 512, ff = 1024
+ * (cosyvoice2 yaml :68-78): other widths return CV_ERR_UNSUPPORTED and the caller keeps the cv_gemm / cv_layernorm path.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cv_tblock_params {
+  int32_t dtype;              /* CV_BF16 / CV_F16: element type of qk, vt, ao, out_act and the packed weights */
+  int32_t R, T;               /* sequences, frames per sequence */
+  int32_t C, inner, ff;       /* 256, 512, 1024 */
+  float* x; int32_t ldx;      /* [R][T][ldx] fp32; read by head, updated in place by tail */
+  float eps;                  /* LayerNorm eps (both norms) */
+  /* head */
+  const float* g1; const float* b1n;      /* norm1 weight / bias [C] */
+  const void* wqkv_p;                     /* packed [Wq; Wk; Wv] (3 * inner rows, K = C), no bias */
+  void* qk; int32_t ldqk;                 /* [R * T][ldqk] */
+  void* vt; int32_t vt_ld;                /* [R][inner / 64][64][vt_ld] */
+  /* tail */
+  const void* ao; int32_t ldao;           /* attention output [R * T][ldao] or NULL */
+  const void* wo_p; const float* bo;      /* packed to_out.0 (C rows, K = inner), bias [C] */
+  const float* g3; const float* b3n;      /* norm3 weight / bias [C] */
+  const void* w1_p; const float* bf1;     /* packed ff.net.0.proj (ff rows, K = C), bias [ff] */
+  const void* w2_p; const float* bf2;     /* packed ff.net.2 (C rows, K = ff), bias [C] */
+  void* out_act; int32_t ldoa;            /* optional 16-bit copy of the block output [R * T][ldoa] */
+} cv_tblock_params;
+int cv_sizeof_tblock_params(void);
+int cv_tblock_head(const cv_tblock_params* p, void* stream);
+int cv_tblock_tail(const cv_tblock_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Layout / elementwise helpers (HBM-bound, coalesced, fp32 math).
  * ------------------------------------------------------------------------------------------ */
 /* x [B][C][T] fp32 (the reference's channel-first tensors) -> out [B][T][ldo] of `dtype` (channels-last; columns

@@ -1,0 +1,150 @@
+"""GPU: the fused row-block kernels of the estimator's BasicTransformerBlock (cv_tblock_head / cv_tblock_tail,
+csrc/flowblock.hip) through the C ABI against a plain PyTorch fp32 restatement of the same ops
+(/root/reference/cosyvoice/flow/components/transformer.py:243-316: pre-LN self-attention projections, to_out + residual,
+LN, Linear + exact-erf GELU + Linear + residual), and the fused estimator against the unfused cv_gemm / cv_layernorm path.
+
+Tolerances: operands (LN output, GELU output, weights) are 16-bit with fp32 accumulation; the fp32 reference rounds the same
+intermediates to the operand type, so what remains is accumulation order and the erfc polynomial (|err| <= 1.5e-7)."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+C, INNER, FF = 256, 512, 1024
+
+
+def _weights(dt, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc)
+    w = dict(g1=1 + 0.1 * r(C), b1=0.1 * r(C), wq=r(INNER, C, sc=C ** -0.5), wk=r(INNER, C, sc=C ** -0.5), wv=r(INNER, C, sc=C ** -0.5),
+             wo=r(C, INNER, sc=INNER ** -0.5), bo=0.1 * r(C), g3=1 + 0.1 * r(C), b3=0.1 * r(C),
+             w1=r(FF, C, sc=C ** -0.5), bf1=0.2 * r(FF), w2=r(C, FF, sc=FF ** -0.5), bf2=0.1 * r(C))
+    for k in ("wq", "wk", "wv", "wo", "w1", "w2"):       # the values the kernels see
+        w[k] = w[k].to(dt).float()
+    return {k: v.cuda() for k, v in w.items()}
+
+
+def _packed(w, dt):
+    from cosyvoice_amd import ops
+    return dict(wqkv_p=ops.pack_skinny(torch.cat([w["wq"], w["wk"], w["wv"]], 0).to(dt).contiguous()),
+                wo_p=ops.pack_skinny(w["wo"].to(dt).contiguous()), w1_p=ops.pack_skinny(w["w1"].to(dt).contiguous()),
+                w2_p=ops.pack_skinny(w["w2"].to(dt).contiguous()))
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("R,T", [(2, 150), (1, 64), (3, 1)])
+def test_head_vs_torch(dt, R, T):
+    from cosyvoice_amd import ops
+    w = _weights(dt)
+    pk = _packed(w, dt)
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(R, T, C, generator=g) * 2 + 0.3).cuda()
+    Tp = (T + 7) // 8 * 8
+    qk = torch.zeros(R, T, 2 * INNER, device="cuda", dtype=dt)
+    vt = torch.zeros(R, INNER // 64, 64, Tp, device="cuda", dtype=dt)
+    p = ops.tblock_params(x, R, T, 1e-5, dt)
+    p.g1, p.b1n, p.wqkv_p = w["g1"].data_ptr(), w["b1"].data_ptr(), pk["wqkv_p"].data_ptr()
+    p.qk, p.ldqk, p.vt, p.vt_ld = qk.data_ptr(), 2 * INNER, vt.data_ptr(), Tp
+    ops.tblock_head(p)
+    torch.cuda.synchronize()
+    xn = F.layer_norm(x, (C,), w["g1"], w["b1"], 1e-5).to(dt).float()
+    ref_qk = torch.cat([xn @ w["wq"].t(), xn @ w["wk"].t()], -1)
+    ref_v = xn @ w["wv"].t()                                         # (R, T, 512)
+    tol = 2e-2 if dt == torch.bfloat16 else 3e-3
+    e_qk = (qk.float() - ref_qk).abs().max().item()
+    got_v = vt[..., :T].float().reshape(R, INNER, T).transpose(1, 2)
+    e_v = (got_v - ref_v).abs().max().item()
+    print(f"head[{dt},{R}x{T}]: qk Linf {e_qk:.3e}  vt Linf {e_v:.3e} (values ~ {ref_qk.abs().mean().item():.2f})")
+    assert e_qk < tol and e_v < tol
+    assert vt[..., T:].abs().max().item() == 0 if Tp > T else True   # the pad columns stay untouched
+
+
+def _tail_ref(x, ao, w, dt):
+    x1 = x if ao is None else x + ao.float() @ w["wo"].t() + w["bo"]
+    xn = F.layer_norm(x1, (C,), w["g3"], w["b3"], 1e-5).to(dt).float()
+    h = F.gelu(xn @ w["w1"].t() + w["bf1"]).to(dt).float()
+    return x1 + h @ w["w2"].t() + w["bf2"]
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("R,T", [(2, 150), (1, 64), (2, 65)])
+@pytest.mark.parametrize("outproj", [True, False])
+def test_tail_vs_torch(dt, R, T, outproj):
+    from cosyvoice_amd import ops
+    w = _weights(dt, seed=2)
+    pk = _packed(w, dt)
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(R, T, C, generator=g) * 2 + 0.3).cuda()
+    ao = torch.randn(R, T, INNER, generator=g).cuda().to(dt)
+    ref = _tail_ref(x, ao if outproj else None, w, dt)
+    xk = x.clone()
+    oa = torch.zeros(R, T, 2 * C, device="cuda", dtype=dt)
+    p = ops.tblock_params(xk, R, T, 1e-5, dt)
+    if outproj:
+        p.ao, p.ldao, p.wo_p, p.bo = ao.data_ptr(), INNER, pk["wo_p"].data_ptr(), w["bo"].data_ptr()
+    p.g3, p.b3n = w["g3"].data_ptr(), w["b3"].data_ptr()
+    p.w1_p, p.bf1, p.w2_p, p.bf2 = pk["w1_p"].data_ptr(), w["bf1"].data_ptr(), pk["w2_p"].data_ptr(), w["bf2"].data_ptr()
+    p.out_act, p.ldoa = oa[:, :, C:].data_ptr(), 2 * C
+    ops.tblock_tail(p)
+    torch.cuda.synchronize()
+    tol = 3e-2 if dt == torch.bfloat16 else 4e-3
+    e = (xk - ref).abs().max().item()
+    e16 = (oa[:, :, C:].float() - ref).abs().max().item()
+    print(f"tail[{dt},{R}x{T},outproj={outproj}]: Linf {e:.3e}  16-bit copy {e16:.3e} (values ~ {ref.abs().mean().item():.2f})")
+    assert e < tol and e16 < tol + (6e-2 if dt == torch.bfloat16 else 8e-3)
+    assert oa[:, :, :C].abs().max().item() == 0
+
+
+def test_gelu_erf_polynomial():
+    """The tail's erfc polynomial against torch's exact GELU over the whole useful range (through a 1-row FFN with identity-like
+    weights is overkill: the tail test above already covers it at 16-bit; this pins the fp32 behaviour through W2 = I)."""
+    from cosyvoice_amd import ops
+    dt = torch.float16
+    w = _weights(dt, seed=5)
+    # LN off (gamma 1, beta 0 on a pre-normalised row is not expressible), so drive the hidden layer directly: W1 = [I; 0], bf1 = sweep
+    w["w1"] = torch.zeros(FF, C).cuda()
+    w["bf1"] = torch.linspace(-8, 8, FF).cuda()
+    w["w2"] = torch.zeros(C, FF).cuda()
+    w["w2"][0, :] = 1.0 / 64                     # column 0 of the output = sum of gelu(sweep) / 64
+    w["bf2"] = torch.zeros(C).cuda()
+    pk = _packed(w, dt)
+    x = torch.randn(1, 64, C).cuda()
+    xk = x.clone()
+    p = ops.tblock_params(xk, 1, 64, 1e-5, dt)
+    p.g3, p.b3n = w["g3"].data_ptr(), w["b3"].data_ptr()
+    p.w1_p, p.bf1, p.w2_p, p.bf2 = pk["w1_p"].data_ptr(), w["bf1"].data_ptr(), pk["w2_p"].data_ptr(), w["bf2"].data_ptr()
+    ops.tblock_tail(p)
+    torch.cuda.synchronize()
+    ref = (F.gelu(w["bf1"]).to(dt).float().sum() / 64).item()
+    got = (xk - x)[0, :, 0]
+    assert (got - ref).abs().max().item() < 2e-3 * max(1.0, abs(ref))
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 6e-3), (torch.bfloat16, 5e-2)])
+def test_fused_estimator_equals_unfused(dt, tol, monkeypatch):
+    """ConditionalDecoder.forward_cl with the row-block kernels vs the cv_gemm / cv_layernorm launches (CV_FLOW_FUSED=0) on the
+    same weights and inputs, tiny depth, T not a multiple of 64, batch of 2 CFG pairs."""
+    from cosyvoice_amd.config import FlowConfig
+    from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
+    from cosyvoice_amd.weights import flow_state_dict
+    cfg = FlowConfig.tiny()
+    flow = CausalMaskedDiffWithXvec(cfg, dtype=dt).load_state_dict(flow_state_dict(cfg))
+    est = flow.decoder.estimator
+    assert est.fused
+    R, T = 4, 150
+    g = torch.Generator().manual_seed(0)
+    xin = torch.randn(R, T, cfg.est_in_channels, generator=g).cuda().to(dt)
+    tt = est.time_table([0.3])
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CV_FLOW_FUSED", flag)
+        ws = est._workspace(R, T)
+        ws["xin"].copy_(xin)
+        outs.append(est.forward_cl(ws, R, tt[0]).clone())
+    torch.cuda.synchronize()
+    d = (outs[0] - outs[1]).abs()
+    print(f"fused vs unfused [{dt}]: Linf {d.max().item():.3e} L1 {d.mean().item():.3e} (values ~ {outs[1].abs().mean().item():.2f})")
+    assert d.max().item() < tol * max(1.0, outs[1].abs().max().item())
