@@ -15,160 +15,236 @@
 //   * weights are pre-packed in MFMA fragment order (cv_pack_skinny: 1 KiB contiguous per fragment) and stream
 //     L2 -> VGPR directly, split over the 4 waves by OUTPUT COLUMN, so every weight byte enters the CU exactly once per
 //     64 rows (64 flop per weight byte instead of 32 per operand byte) and never touches LDS;
-//   * a two-slot register ring (8 fragments each) keeps two fragment groups in flight behind the MFMAs;
+//   * a register ring of NS slots (8 fragments = 32 MFMA-steps of work each) keeps NS - 1 fragment groups in flight behind
+//     the MFMAs.  First version: 2 slots at two waves per SIMD -> one group (512 cycles) of cover against a loaded L2
+//     latency of 1-2 us, the kernels ran latency-bound (42 / 48 us per call at batch 8).  Now NS = 6 slots at ONE wave per
+//     SIMD: the MFMA accumulators move to the AGPR half of the 512-register file, which leaves the 256 architectural
+//     VGPRs to the ring (192), the operand fragments and addressing; 5 groups = 2 500 cycles of cover, 160 KB in flight
+//     per CU.  (hipcc does not place load destinations in AGPRs: an 8-slot ring was spilled to scratch inside the loop.)
 //   * the 1024-wide GELU intermediate never leaves the CU (128-column chunks through a double-buffered LDS tile),
 //     the residual row stays in the accumulators from the out-projection to the final store, and LayerNorm(norm3)
 //     is computed from those accumulators (cross-wave row statistics through 2 KiB of LDS).
+// hipcc notes (ROCm 7.2): every ring refill is pinned with sched_barrier(0) — left alone, the scheduler sinks a refill to
+// just before its use (the slot's registers are dead in between) and the prefetch distance collapses to zero; a batch of
+// row loads is pinned with an empty asm that redefines all 16 registers — otherwise each load is sunk to its row's arithmetic
+// (16 dependent L2 round trips); small global loads inside the chunk loop (bias) are likewise sunk behind the weight
+// prefetch and drain it with vmcnt(0), so the hidden-layer bias is staged in LDS; the head's stores are raw buffer stores
+// (rows beyond T dropped by the bounds check) because stores under an exec-masked branch make the in-order vmcnt
+// bookkeeping of the prefetched loads conservative.
 #include "cv_device.h"
+#include <cstdlib>
 
 namespace {
 
 constexpr int TB_C = 256, TB_INNER = 512, TB_FF = 1024;
 constexpr int BM = 64;        // rows per workgroup (4 MFMA row tiles)
 constexpr int HC = 128;       // hidden columns per FFN chunk
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
 // 16-byte chunk slot of (row, chunk) in an operand image whose rows hold >= 16 chunks: XOR the low 4 chunk bits with row & 15.
 // A ds_read_b128 fragment (lane l: row l & 15, chunk 4 ks + (l >> 4)) then hits 16 distinct slots per 16-lane group.
 __device__ __forceinline__ int swz16(int row, int chunk) { return (chunk & ~15) | ((chunk ^ row) & 15); }
 
-// exact-erf GELU (diffusers GELU(approximate="none")): erfc by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the
-// 16-bit rounding of the result), negative side computed as 0.5 x erfc(|z|) so there is no 1 - erf cancellation.
-// ~14 VALU instead of ocml erff's ~40 with branches: the FFN evaluates 1024 of these per row per block.
+// exact-erf GELU (diffusers GELU(approximate="none")) = relu(x) - 0.5 |x| erfc(|x| / sqrt 2), erfc by Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7, far below the 16-bit rounding of the result; no 1 - erf cancellation on the negative side).
+// 13 VALU + 2 transcendental instead of ocml erff's ~40 with branches: the FFN evaluates 1024 of these per row per block.
 __device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));
+  const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.4426950408889634f));   // exp(-x^2 / 2)
   float pl = fmaf(1.061405429f, t, -1.453152027f);
   pl = fmaf(pl, t, 1.421413741f);
   pl = fmaf(pl, t, -0.284496736f);
   pl = fmaf(pl, t, 0.254829592f);
-  const float erfc_abs = pl * t * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);   // erfc(|z|)
-  const float cdf2 = x < 0.f ? erfc_abs : 2.0f - erfc_abs;                                  // 1 + erf(z)
-  return 0.5f * x * cdf2;
+  const float erfc_abs = pl * t * e;
+  return fmaf(-0.5f * ax, erfc_abs, fmaxf(x, 0.f));
 }
+
+#define PIN16(v)                                                                                                      \
+  asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), \
+               "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]))
 
 template <int DT>
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
   return make_uint2(pack2<DT>(a, b), pack2<DT>(c, d));
 }
 
+// sum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15), every lane gets the total: 4 v_add_f32_dpp, no LDS crossbar
+__device__ __forceinline__ float row16_sum(float v) {
+  v += bitcast<float>(__builtin_amdgcn_update_dpp(0, bitcast<int>(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += bitcast<float>(__builtin_amdgcn_update_dpp(0, bitcast<int>(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += bitcast<float>(__builtin_amdgcn_update_dpp(0, bitcast<int>(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += bitcast<float>(__builtin_amdgcn_update_dpp(0, bitcast<int>(v), 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
+
 // LayerNorm of this workgroup's 64 rows straight from global memory into the K = 256 operand image (512-byte rows):
-// wave w normalises rows 16w .. 16w+15, one row per wave-instruction (lane = 4 consecutive columns), two-pass in registers.
+// wave w normalises rows 16 w .. 16 w + 15, four rows per pass, 16 lanes per row (lane sub = l & 15 holds columns
+// 64 k + 4 sub ..+3, k < 4: 256-byte coalesced segments), two-pass in registers, row sums by DPP.
 // Rows beyond T re-read row T-1 (finite values; their results are never stored).
 template <int DT>
 __device__ __forceinline__ void ln_rows_to_lds(const float* xs, int ldx, int t0, int T, const float* gamma, const float* beta,
                                                float eps, char* img, int wid, int lane) {
-  const float4 g4 = *(const float4*)(gamma + 4 * lane);
-  const float4 b4 = *(const float4*)(beta + 4 * lane);
-  float4 v[16];
+  const int sub = lane & 15, rr = lane >> 4;
+  f32x4_t v[16];   // [pass][k]
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int t = min(t0 + wid * 16 + i, T - 1);
-    v[i] = *(const float4*)(xs + (int64_t)t * ldx + 4 * lane);
+  for (int ps = 0; ps < 4; ++ps) {
+    const int t = min(t0 + wid * 16 + ps * 4 + rr, T - 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[ps * 4 + k] = *(const f32x4_t*)(xs + (int64_t)t * ldx + 64 * k + 4 * sub);
   }
+  float4 g4[4], b4[4];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const float mean = wave_sum((v[i].x + v[i].y) + (v[i].z + v[i].w)) * (1.0f / TB_C);
-    const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-    const float rstd = rsqrtf(wave_sum((a * a + b * b) + (c * c + d * d)) * (1.0f / TB_C) + eps);
-    const int row = wid * 16 + i;
-    *(uint2*)(img + row * 512 + (swz16(row, lane >> 1) << 4) + ((lane & 1) << 3)) =
-        pack4<DT>(a * rstd * g4.x + b4.x, b * rstd * g4.y + b4.y, c * rstd * g4.z + b4.z, d * rstd * g4.w + b4.w);
+  for (int k = 0; k < 4; ++k) {
+    g4[k] = *(const float4*)(gamma + 64 * k + 4 * sub);
+    b4[k] = *(const float4*)(beta + 64 * k + 4 * sub);
+  }
+  // all 16 row loads in flight before the first reduction: hipcc otherwise sinks every load to its row's arithmetic and pays
+  // 16 dependent L2 round trips.  The empty statement "redefines" the 16 registers, so every load has to precede it.
+  PIN16(v);
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += (v[ps * 4 + k][0] + v[ps * 4 + k][1]) + (v[ps * 4 + k][2] + v[ps * 4 + k][3]);
+    const float mean = row16_sum(s) * (1.0f / TB_C);
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[ps * 4 + k][e] - mean; v[ps * 4 + k][e] = d; q += d * d; }
+    const float rstd = rsqrtf(row16_sum(q) * (1.0f / TB_C) + eps);
+    const int row = wid * 16 + ps * 4 + rr;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      *(uint2*)(img + row * 512 + (swz16(row, 8 * k + (sub >> 1)) << 4) + ((sub & 1) << 3)) =
+          pack4<DT>(v[ps * 4 + k][0] * rstd * g4[k].x + b4[k].x, v[ps * 4 + k][1] * rstd * g4[k].y + b4[k].y,
+                    v[ps * 4 + k][2] * rstd * g4[k].z + b4[k].z, v[ps * 4 + k][3] * rstd * g4[k].w + b4[k].w);
   }
 }
 
 // ============================================================================================== head: LN -> Q | K | V^T
 // Output columns: 1536 = 96 MFMA tiles (0..63 = [Q | K] row-major, 64..95 = V, stored transposed).  A wave-step is 4
-// consecutive tiles x all 8 k-steps x the 4 row tiles (128 MFMAs); wave w takes tile groups w, w + 4, ... (6 steps).
-// V steps swap the MFMA operands (D = xn . Wv^T has the frame index in the registers), so a lane holds 4 consecutive
-// frames of one (head, channel) row of V^T: 8-byte stores, no transposing pass.
-template <int DT>
-__global__ __launch_bounds__(256, 2) void tblock_head_kernel(const cv_tblock_params p) {
+// consecutive tiles x all 8 k-steps x the 4 row tiles (128 MFMAs = 4 fragment groups of 2 k-steps); wave w takes tile
+// groups w, w + 4, ... (6 steps).  V steps swap the MFMA operands (D = xn . Wv^T has the frame index in the registers),
+// so a lane holds 4 consecutive frames of one (head, channel) row of V^T: 8-byte stores, no transposing pass.
+constexpr int ring_body(int ns) { return ns == 4 ? 1 : (ns == 6 ? 3 : (ns == 8 ? 2 : 0)); }   // lcm(NS, 4) / 4 steps or chunks
+
+template <int DT, int NS, bool FULLU, int ABL = 0>   // ABL: timing-only ablations (1: no output stores, 2: no ring refills)
+__global__ __launch_bounds__(256, 1) void tblock_head_kernel(const cv_tblock_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lq = lane & 15, lg = lane >> 4;
   const int r = blockIdx.y, t0 = blockIdx.x * BM;
   const float* xs = p.x + (int64_t)r * p.T * p.ldx;
-  constexpr int NKS = TB_C / 32;   // 8
+  constexpr int NKS = TB_C / 32;                  // 8 k-steps
+  constexpr int NSTEP = 3 * TB_INNER / 16 / 16;   // 96 tiles / (4 waves x 4 tiles) = 6
+  constexpr int SPB = ring_body(NS);              // steps per loop body: group G = 4 step + k-quarter lives in slot G % NS
+  static_assert(SPB > 0 && NSTEP % SPB == 0, "ring depth must divide the group count");
 
   const uint4* Wl = (const uint4*)p.wqkv_p + lane;
-  uint4 s0[8], s1[8];
-  auto ld = [&](uint4 (&s)[8], int tile0, int kq) {
+  uint4 s[NS][8];
+  // fragment group G (clamped to the last step: harmless re-reads at the end): tiles (4 step + w) * 4 + j, k-steps 2 kq + u
+  auto ld = [&](uint4 (&sl)[8], int G) {
+    if ((ABL & 2) && G >= NS) return;
+    const int st = min(G >> 2, NSTEP - 1), kq = G & 3;
+    const int tile0 = (st * 4 + wid) * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) s[j * 2 + u] = Wl[((tile0 + j) * NKS + kq * 2 + u) * 64];
+      for (int u = 0; u < 2; ++u) sl[j * 2 + u] = Wl[((tile0 + j) * NKS + kq * 2 + u) * 64];
+    __builtin_amdgcn_sched_barrier(0);   // ring refills stay where they are written: NS - 1 fragment groups ahead of their use
   };
-  ld(s0, wid * 4, 0);   // the first two fragment groups fly during the LayerNorm
-  ld(s1, wid * 4, 1);
-
+#pragma unroll
+  for (int g = 0; g < NS / 2; ++g) ld(s[g], g);          // half of the ring flies during the LayerNorm (register budget)
   ln_rows_to_lds<DT>(xs, p.ldx, t0, p.T, p.g1, p.b1n, p.eps, smem, wid, lane);
+#pragma unroll
+  for (int g = NS / 2; g < NS; ++g) ld(s[g], g);
   __syncthreads();
 
-  int aoff[4];   // byte offset of this lane's fragment chunk for k-step 0 of row tile i (k-step ks: chunk 4 ks + lg)
-#pragma unroll
-  for (int i = 0; i < 4; ++i) aoff[i] = (16 * i + lq) * 512;
-
   f32x4_t acc[4][4];
-  auto compute = [&](uint4 (&s)[8], int kq, bool vpart) {
+  auto compute = [&](uint4 (&sl)[8], int kq, bool vpart) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int ks = kq * 2 + u;
       uint4 a[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = *(const uint4*)(smem + aoff[i] + (swz16(lq, ks * 4 + lg) << 4));
+      for (int i = 0; i < 4; ++i) a[i] = *(const uint4*)(smem + (16 * i + lq) * 512 + (swz16(lq, ks * 4 + lg) << 4));
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          acc[i][j] = vpart ? mfma_block<DT>(a[i], s[j * 2 + u], acc[i][j]) : mfma_block<DT>(s[j * 2 + u], a[i], acc[i][j]);
+          acc[i][j] = vpart ? mfma_block<DT>(a[i], sl[j * 2 + u], acc[i][j]) : mfma_block<DT>(sl[j * 2 + u], a[i], acc[i][j]);
     }
+    __builtin_amdgcn_sched_barrier(0);
   };
 
-  constexpr int NSTEP = 3 * TB_INNER / 16 / 16;   // 96 tiles / (4 waves x 4 tiles) = 6
-  uint16_t* qk = (uint16_t*)p.qk + (int64_t)r * p.T * p.ldqk;
-  uint16_t* vt = (uint16_t*)p.vt + (int64_t)r * (TB_INNER / 64) * 64 * p.vt_ld;
-  for (int st = 0; st < NSTEP; ++st) {
-    const int tile0 = (st * 4 + wid) * 4;
-    const int ntile0 = (min(st + 1, NSTEP - 1) * 4 + wid) * 4;
-    const bool vpart = tile0 >= (2 * TB_INNER) / 16;   // wave-uniform
+  // stores go through buffer descriptors of this sequence's [Q | K] rows / V^T block: rows beyond T fall outside the
+  // descriptor and are dropped by the hardware bounds check (no exec-masked branches around the stores)
+  const __amdgpu_buffer_rsrc_t qk_rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((uint16_t*)p.qk + (int64_t)r * p.T * p.ldqk), 0, p.T * p.ldqk * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vt_rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((uint16_t*)p.vt + (int64_t)r * TB_INNER * p.vt_ld), 0, TB_INNER * p.vt_ld * 2, 0x00020000);
+  const bool t_mod4 = (p.T & 3) != 0;
+
+  // fully unrolled (6 steps): across a loop back-edge hipcc merges the pending-load state of the entry edge (ring drained or
+  // not) with the steady state and falls back to conservative vmcnt values that drain most of the ring once per iteration
+#pragma unroll(FULLU ? 8 : 1)
+  for (int st0 = 0; st0 < NSTEP; st0 += SPB) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int ss = 0; ss < SPB; ++ss) {
+      const int st = st0 + ss;
+      const int tile0 = (st * 4 + wid) * 4;
+      const bool vpart = tile0 >= (2 * TB_INNER) / 16;               // wave-uniform
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if (!vpart) {
-      compute(s0, 0, false); ld(s0, tile0, 2);
-      compute(s1, 1, false); ld(s1, tile0, 3);
-      compute(s0, 2, false); ld(s0, ntile0, 0);
-      compute(s1, 3, false); ld(s1, ntile0, 1);
-      // D rows = output column: lane holds row m = 16 i + lq, columns n .. n + 3
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int t = t0 + 16 * i + lq;
-        if (t >= p.T) continue;
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (!vpart) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          *(uint2*)(qk + (int64_t)t * p.ldqk + (tile0 + j) * 16 + 4 * lg) = pack4<DT>(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-      }
-    } else {
-      compute(s0, 0, true); ld(s0, tile0, 2);
-      compute(s1, 1, true); ld(s1, tile0, 3);
-      compute(s0, 2, true); ld(s0, ntile0, 0);
-      compute(s1, 3, true); ld(s1, ntile0, 1);
-      // D rows = frame: lane holds V^T row (head * 64 + d) = column tile * 16 + lq, frames t .. t + 3
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int vrow = (tile0 + j) * 16 + lq - 2 * TB_INNER;
-        uint16_t* dst = vt + (int64_t)vrow * p.vt_ld;
+        for (int kq = 0; kq < 4; ++kq) { compute(s[(ss * 4 + kq) % NS], kq, false); ld(s[(ss * 4 + kq) % NS], st * 4 + kq + NS); }
+        // D rows = output column: lane holds row m = 16 i + lq, columns n .. n + 3
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int t = t0 + 16 * i + 4 * lg;
-          if (t + 3 < p.T) {
-            *(uint2*)(dst + t) = pack4<DT>(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-          } else {
+          const int t = t0 + 16 * i + lq;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (t + e < p.T) dst[t + e] = Elem16<DT>::from_f32(acc[i][j][e]);
+          for (int j = 0; j < 4; ++j) {
+            const uint2 u = pack4<DT>(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            if (ABL & 1) { asm volatile("" :: "v"(u.x), "v"(u.y)); continue; }
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{u.x, u.y}, qk_rs, (t * p.ldqk + (tile0 + j) * 16 + 4 * lg) * 2, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) { compute(s[(ss * 4 + kq) % NS], kq, true); ld(s[(ss * 4 + kq) % NS], st * 4 + kq + NS); }
+        // D rows = frame: lane holds V^T row (head * 64 + d) = column tile * 16 + lq, frames t .. t + 3
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int vrow = (tile0 + j) * 16 + lq - 2 * TB_INNER;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int t = t0 + 16 * i + 4 * lg;
+            const uint2 u = pack4<DT>(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            const int off = (vrow * p.vt_ld + t) * 2;
+            if (ABL & 1) { asm volatile("" :: "v"(u.x), "v"(u.y)); continue; }
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{u.x, u.y}, vt_rs, (t + 3 < p.T) ? off : 0x7FFFFFF0, 0, 0);
+          }
+        }
+        if (t_mod4) {   // T not a multiple of 4 (the v1 flow's odd lengths): the group that straddles T, element by element
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int vrow = (tile0 + j) * 16 + lq - 2 * TB_INNER;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int t = t0 + 16 * i + 4 * lg;
+              const bool straddle = (t < p.T) && (t + 3 >= p.T);
+#pragma unroll
+              for (int e = 0; e < 3; ++e)
+                __builtin_amdgcn_raw_buffer_store_b16((short)Elem16<DT>::from_f32(acc[i][j][e]), vt_rs,
+                                                      (straddle && t + e < p.T) ? (vrow * p.vt_ld + t + e) * 2 : 0x7FFFFFF0, 0, 0);
+            }
           }
         }
       }
@@ -178,10 +254,14 @@ __global__ __launch_bounds__(256, 2) void tblock_head_kernel(const cv_tblock_par
 
 // ============================================================================================== tail: to_out + LN + FFN
 // LDS: [0, 64 K) attention-output image (64 rows x 1024 B) during the out-projection, afterwards xn image (64 x 512 B) at 0
-// and the two GELU chunk tiles (64 x 256 B each) at 32 K / 48 K; [64 K, 66 K) cross-wave row statistics; [66 K, 70 K) bf1.
+// and the two GELU chunk tiles (64 x 256 B each) at 32 K / 48 K; [64 K, 66 K) cross-wave row statistics; [66 K, 70 K) bf1; [70 K, 74 K) bo, g3, b3n, bf2.
 // Wave w owns output columns [64 w, 64 w + 64) of the 256-wide residual row for the whole kernel (acc2: 4 x 4 tiles).
-template <int DT, bool OUTPROJ>
-__global__ __launch_bounds__(256, 2) void tblock_tail_kernel(const cv_tblock_params p) {
+// Fragment-group sequence of a wave: 8 out-projection groups (4 tiles x 2 k-steps), then per 128-column hidden chunk c the
+// groups q = 0, 1 (hidden layer: 2 tiles x k-steps 4 q ..+3) and q = 2, 3 (output layer: 4 tiles x k-steps 4 c + 2 (q - 2) ..+1);
+// The wave's groups are numbered through (out-projection 0..7 when present, then FFN group f = 4 c + q); group G lives in ring
+// slot G % NS and, once computed, its slot is refilled with group G + NS.
+template <int DT, bool OUTPROJ, int NS, bool FULLU, int ABL = 0>   // ABL: timing-only ablations (1: GELU -> identity, 2: no ring refills)
+__global__ __launch_bounds__(256, 1) void tblock_tail_kernel(const cv_tblock_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ximg = smem;
   char* himg = smem + 32768;
@@ -194,24 +274,37 @@ __global__ __launch_bounds__(256, 2) void tblock_tail_kernel(const cv_tblock_par
   const int r = blockIdx.y, t0 = blockIdx.x * BM;
   float* xs = p.x + (int64_t)r * p.T * p.ldx;
   const int ncol0 = wid * 64;
+  constexpr int NC = TB_FF / HC;        // 8 chunks
+  constexpr int CPB = ring_body(NS);    // chunks per loop body (slot indices repeat every lcm(NS, 4) groups)
+  constexpr int GOFF = OUTPROJ ? 8 : 0; // number of the first FFN group
+  static_assert(CPB > 0, "unsupported ring depth");
   ((float4*)(smem + 65536 + 2048))[tid] = ((const float4*)p.bf1)[tid];   // 1024 floats; visible after the first barrier
+  // the 256-wide vectors of the middle of the kernel (to_out bias, norm3 weight / bias, output bias) likewise: loaded here, ahead
+  // of the weight ring in the in-order vmcnt queue, read back from LDS where they are needed
+  float* vecs = (float*)(smem + 65536 + 2048 + 4096);   // [4][256]: bo | g3 | b3n | bf2
+  vecs[tid] = OUTPROJ ? p.bo[tid] : 0.f;
+  vecs[256 + tid] = p.g3[tid];
+  vecs[512 + tid] = p.b3n[tid];
+  vecs[768 + tid] = p.bf2[tid];
 
   const uint4* W1l = (const uint4*)p.w1_p + lane;   // [64 tiles][8 ks]
   const uint4* W2l = (const uint4*)p.w2_p + lane;   // [16 tiles][32 ks]
-  uint4 s0[8], s1[8];
-  // FFN fragment groups.  GEMM1 (chunk c, half hf): hidden tiles 8 c + 2 w + j (j < 2), k-steps 4 hf + u (u < 4): s[j * 4 + u]
-  auto ld_g1 = [&](uint4 (&s)[8], int c, int hf) {
+  uint4 s[NS][8];
+  auto ld_ffn = [&](uint4 (&sl)[8], int f) {   // FFN group f = 4 c + q (clamped to the last chunk: harmless re-reads at the end)
+    if ((ABL & 2) && f >= NS) return;
+    const int c = min(f >> 2, NC - 1), q = f & 3;
+    if (q < 2) {   // hidden tiles 8 c + 2 w + j (j < 2), k-steps 4 q + u (u < 4): sl[j * 4 + u]
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) s[j * 4 + u] = W1l[((8 * c + 2 * wid + j) * (TB_C / 32) + 4 * hf + u) * 64];
-  };
-  // GEMM2 (chunk c, half hf): output tiles 4 w + j (j < 4), k-steps 4 c + 2 hf + u (u < 2): s[j * 2 + u]
-  auto ld_g2 = [&](uint4 (&s)[8], int c, int hf) {
+        for (int u = 0; u < 4; ++u) sl[j * 4 + u] = W1l[((8 * c + 2 * wid + j) * (TB_C / 32) + 4 * q + u) * 64];
+    } else {       // output tiles 4 w + j (j < 4), k-steps 4 c + 2 (q - 2) + u (u < 2): sl[j * 2 + u]
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) s[j * 2 + u] = W2l[((4 * wid + j) * (TB_FF / 32) + 4 * c + 2 * hf + u) * 64];
+        for (int u = 0; u < 2; ++u) sl[j * 2 + u] = W2l[((4 * wid + j) * (TB_FF / 32) + 4 * c + 2 * (q - 2) + u) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   // residual rows in the accumulator layout (row 16 i + lq, columns ncol0 + 16 j + 4 lg ..+3)
@@ -221,42 +314,43 @@ __global__ __launch_bounds__(256, 2) void tblock_tail_kernel(const cv_tblock_par
     for (int i = 0; i < 4; ++i) {
       const int t = min(t0 + 16 * i + lq, p.T - 1);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 v = *(const float4*)(xs + (int64_t)t * p.ldx + ncol0 + 16 * j + 4 * lg);
-        acc2[i][j] = f32x4_t{v.x, v.y, v.z, v.w};
-      }
+      for (int j = 0; j < 4; ++j) acc2[i][j] = *(const f32x4_t*)(xs + (int64_t)t * p.ldx + ncol0 + 16 * j + 4 * lg);
     }
   };
 
   if constexpr (OUTPROJ) {
-    // ---- attention output tile -> LDS operand image (1024-byte rows), one row per wave-instruction
     const uint16_t* aos = (const uint16_t*)p.ao + (int64_t)r * p.T * p.ldao;
     const uint4* Wol = (const uint4*)p.wo_p + lane;   // [16 tiles][16 ks]
-    auto ld_o = [&](uint4 (&s)[8], int g) {           // group g: tiles 4 w + j, k-steps 2 g + u
+    auto ld_o = [&](uint4 (&sl)[8], int g) {          // group g: tiles 4 w + j, k-steps 2 g + u
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) s[j * 2 + u] = Wol[((4 * wid + j) * (TB_INNER / 32) + 2 * g + u) * 64];
+        for (int u = 0; u < 2; ++u) sl[j * 2 + u] = Wol[((4 * wid + j) * (TB_INNER / 32) + 2 * g + u) * 64];
+      __builtin_amdgcn_sched_barrier(0);
     };
     {
-      uint4 v[16];
+      // ---- attention output tile -> LDS operand image (1024-byte rows), one row per wave-instruction
+      u32x4_t v[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int t = min(t0 + wid * 16 + i, p.T - 1);
-        v[i] = *(const uint4*)(aos + (int64_t)t * p.ldao + lane * 8);
+        v[i] = *(const u32x4_t*)(aos + (int64_t)t * p.ldao + lane * 8);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < NS / 2; ++g) ld_o(s[g], g);   // half of the ring behind the tile loads (register budget), the rest below
+      PIN16(v);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = wid * 16 + i;
-        *(uint4*)(smem + row * 1024 + (swz16(row, lane) << 4)) = v[i];
+        *(u32x4_t*)(smem + row * 1024 + (swz16(row, lane) << 4)) = v[i];
       }
     }
-    // (the 16 staging registers are dead before the residual rows and the first weight groups are requested: 256-VGPR budget)
+#pragma unroll
+    for (int g = NS / 2; g < NS; ++g) ld_o(s[g], g);
     load_residual();
-    ld_o(s0, 0);
-    ld_o(s1, 1);
     __syncthreads();
-    auto compute_o = [&](uint4 (&s)[8], int g) {
+    auto compute_o = [&](uint4 (&sl)[8], int g) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int ks = 2 * g + u;
@@ -266,38 +360,37 @@ __global__ __launch_bounds__(256, 2) void tblock_tail_kernel(const cv_tblock_par
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc2[i][j] = mfma_block<DT>(s[j * 2 + u], a[i], acc2[i][j]);
+          for (int i = 0; i < 4; ++i) acc2[i][j] = mfma_block<DT>(sl[j * 2 + u], a[i], acc2[i][j]);
       }
+      __builtin_amdgcn_sched_barrier(0);
     };
-    compute_o(s0, 0); ld_o(s0, 2);
-    compute_o(s1, 1); ld_o(s1, 3);
-    compute_o(s0, 2); ld_o(s0, 4);
-    compute_o(s1, 3); ld_o(s1, 5);
-    compute_o(s0, 4); ld_o(s0, 6);
-    compute_o(s1, 5); ld_o(s1, 7);
-    compute_o(s0, 6); ld_g1(s0, 0, 0);
-    compute_o(s1, 7); ld_g1(s1, 0, 1);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      compute_o(s[g % NS], g);
+      if (g + NS < 8) ld_o(s[g % NS], g + NS);
+      else ld_ffn(s[g % NS], g + NS - 8);   // the first FFN groups fly during the LayerNorm
+    }
 
     // ---- + to_out bias: acc2 is now the block's first residual output x1; LayerNorm(norm3) from the accumulators
     float4 gam[4], bet[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = ncol0 + 16 * j + 4 * lg;
-      const float4 bo = *(const float4*)(p.bo + n);
-      gam[j] = *(const float4*)(p.g3 + n);
-      bet[j] = *(const float4*)(p.b3n + n);
+      const float4 bo = *(const float4*)(vecs + n);
+      gam[j] = *(const float4*)(vecs + 256 + n);
+      bet[j] = *(const float4*)(vecs + 512 + n);
 #pragma unroll
       for (int i = 0; i < 4; ++i) { acc2[i][j][0] += bo.x; acc2[i][j][1] += bo.y; acc2[i][j][2] += bo.z; acc2[i][j][3] += bo.w; }
     }
     float mean[4], rstd[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float s = 0.f;
+      float sm = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) s += (acc2[i][j][0] + acc2[i][j][1]) + (acc2[i][j][2] + acc2[i][j][3]);
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
-      if (lg == 0) red[wid * 64 + 16 * i + lq] = s;
+      for (int j = 0; j < 4; ++j) sm += (acc2[i][j][0] + acc2[i][j][1]) + (acc2[i][j][2] + acc2[i][j][3]);
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      if (lg == 0) red[wid * 64 + 16 * i + lq] = sm;
     }
     __syncthreads();   // also: every wave is done reading the attention-output image
 #pragma unroll
@@ -328,74 +421,83 @@ __global__ __launch_bounds__(256, 2) void tblock_tail_kernel(const cv_tblock_par
       }
     }
   } else {
-    ld_g1(s0, 0, 0);
-    ld_g1(s1, 0, 1);
-    load_residual();
+#pragma unroll
+    for (int f = 0; f < NS / 2; ++f) ld_ffn(s[f], f);
     ln_rows_to_lds<DT>(xs, p.ldx, t0, p.T, p.g3, p.b3n, p.eps, ximg, wid, lane);
+#pragma unroll
+    for (int f = NS / 2; f < NS; ++f) ld_ffn(s[f], f);
+    load_residual();
   }
   // + FFN output bias: the accumulators then collect x1 + b2 + sum_c gelu(..) . W2_c^T
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float4 b2 = *(const float4*)(p.bf2 + ncol0 + 16 * j + 4 * lg);
+    const float4 b2 = *(const float4*)(vecs + 768 + ncol0 + 16 * j + 4 * lg);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { acc2[i][j][0] += b2.x; acc2[i][j][1] += b2.y; acc2[i][j][2] += b2.z; acc2[i][j][3] += b2.w; }
   }
   __syncthreads();   // xn image complete
 
-  constexpr int NC = TB_FF / HC;   // 8 chunks
-  for (int c = 0; c < NC; ++c) {
-    const int cn = min(c + 1, NC - 1);
-    char* hb = himg + (c & 1) * 16384;
-    // the accumulators of the hidden layer start from its bias (this wave's two tiles of the chunk)
-    f32x4_t acc1[4][2];
+#pragma unroll(FULLU ? 8 : 1)   // no loop back-edge: exact vmcnt bookkeeping for the ring (see the head kernel)
+  for (int c0 = 0; c0 < NC; c0 += CPB) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const float4 b1v = *(const float4*)(b1s + c * HC + (2 * wid + j) * 16 + 4 * lg);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc1[i][j] = f32x4_t{b1v.x, b1v.y, b1v.z, b1v.w};
-    }
-    auto compute_g1 = [&](uint4 (&s)[8], int hf) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int ks = 4 * hf + u;
-        uint4 a[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = *(const uint4*)(ximg + (16 * i + lq) * 512 + (swz16(lq, ks * 4 + lg) << 4));
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc1[i][j] = mfma_block<DT>(s[j * 4 + u], a[i], acc1[i][j]);
-      }
-    };
-    auto compute_g2 = [&](uint4 (&s)[8], int hf) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int ks = 2 * hf + u;   // k-step inside the chunk (4 x 32 = 128 hidden columns)
-        uint4 a[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = *(const uint4*)(hb + (16 * i + lq) * 256 + (swz16(lq, ks * 4 + lg) << 4));
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc2[i][j] = mfma_block<DT>(s[j * 2 + u], a[i], acc2[i][j]);
-      }
-    };
-    compute_g1(s0, 0); ld_g2(s0, c, 0);
-    compute_g1(s1, 1); ld_g2(s1, c, 1);
-    // bias + GELU -> 16-bit chunk tile (row 16 i + lq, hidden columns (2 w + j) * 16 + 4 lg ..+3 of the chunk)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = 16 * i + lq;
+    for (int cc = 0; cc < CPB; ++cc) {
+      const int c = c0 + cc;
+      if (c >= NC) break;                    // uniform (NC is not a multiple of a 3-chunk body)
+      char* hb = himg + (c & 1) * 16384;
+      // the accumulators of the hidden layer start from its bias (this wave's two tiles of the chunk)
+      f32x4_t acc1[4][2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int ch = (2 * wid + j) * 2 + (lg >> 1);
-        *(uint2*)(hb + m * 256 + (swz16(m, ch) << 4) + ((lg & 1) << 3)) =
-            pack4<DT>(gelu_erf(acc1[i][j][0]), gelu_erf(acc1[i][j][1]), gelu_erf(acc1[i][j][2]), gelu_erf(acc1[i][j][3]));
+        const float4 b1v = *(const float4*)(b1s + c * HC + (2 * wid + j) * 16 + 4 * lg);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc1[i][j] = f32x4_t{b1v.x, b1v.y, b1v.z, b1v.w};
       }
+      auto compute_g1 = [&](uint4 (&sl)[8], int hf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int ks = 4 * hf + u;
+          uint4 a[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) a[i] = *(const uint4*)(ximg + (16 * i + lq) * 512 + (swz16(lq, ks * 4 + lg) << 4));
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc1[i][j] = mfma_block<DT>(sl[j * 4 + u], a[i], acc1[i][j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto compute_g2 = [&](uint4 (&sl)[8], int hf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int ks = 2 * hf + u;   // k-step inside the chunk (4 x 32 = 128 hidden columns)
+          uint4 a[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) a[i] = *(const uint4*)(hb + (16 * i + lq) * 256 + (swz16(lq, ks * 4 + lg) << 4));
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc2[i][j] = mfma_block<DT>(sl[j * 2 + u], a[i], acc2[i][j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      compute_g1(s[(GOFF + cc * 4 + 0) % NS], 0); ld_ffn(s[(GOFF + cc * 4 + 0) % NS], 4 * c + 0 + NS);
+      compute_g1(s[(GOFF + cc * 4 + 1) % NS], 1); ld_ffn(s[(GOFF + cc * 4 + 1) % NS], 4 * c + 1 + NS);
+      // GELU -> 16-bit chunk tile (row 16 i + lq, hidden columns (2 w + j) * 16 + 4 lg ..+3 of the chunk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = 16 * i + lq;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int ch = (2 * wid + j) * 2 + (lg >> 1);
+          *(uint2*)(hb + m * 256 + (swz16(m, ch) << 4) + ((lg & 1) << 3)) =
+              (ABL & 1) ? pack4<DT>(acc1[i][j][0], acc1[i][j][1], acc1[i][j][2], acc1[i][j][3]) :
+              pack4<DT>(gelu_erf(acc1[i][j][0]), gelu_erf(acc1[i][j][1]), gelu_erf(acc1[i][j][2]), gelu_erf(acc1[i][j][3]));
+        }
+      }
+      __syncthreads();   // one barrier per chunk: the next chunk's GELU tile goes to the other buffer
+      compute_g2(s[(GOFF + cc * 4 + 2) % NS], 0); ld_ffn(s[(GOFF + cc * 4 + 2) % NS], 4 * c + 2 + NS);
+      compute_g2(s[(GOFF + cc * 4 + 3) % NS], 1); ld_ffn(s[(GOFF + cc * 4 + 3) % NS], 4 * c + 3 + NS);
     }
-    __syncthreads();   // one barrier per chunk: the next chunk's GELU tile goes to the other buffer
-    compute_g2(s0, 0); ld_g1(s0, cn, 0);
-    compute_g2(s1, 1); ld_g1(s1, cn, 1);
   }
 
   // ---- store the block output (fp32 residual stream, in place) + optional 16-bit copy (skip connection / next conv operand)
@@ -420,6 +522,54 @@ int check_common(const cv_tblock_params& p) {
   return CV_OK;
 }
 
+// ring depth (one wave per SIMD either way): 6 slots by default; CV_TBLOCK_RING=4 selects the 4-slot form; CV_TBLOCK_UNROLL=0 keeps
+// the step / chunk loops rolled (tuning aids)
+int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+int ring_slots() { static int v = env_int("CV_TBLOCK_RING", 6) == 4 ? 4 : 6; return v; }
+bool full_unroll() { static bool v = env_int("CV_TBLOCK_UNROLL", 1) != 0; return v; }
+
+template <typename K>
+void set_lds(K kern, size_t lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
+
+template <int DT, int NS, bool FU>
+void launch_head(const cv_tblock_params& p, dim3 grid, hipStream_t st) {
+  hipLaunchKernelGGL((tblock_head_kernel<DT, NS, FU>), grid, dim3(256), 32768, st, p);
+}
+constexpr size_t TAIL_LDS = 65536 + 2048 + 4096 + 4096;
+template <int DT, bool OP, int NS, bool FU>
+void launch_tail(const cv_tblock_params& p, dim3 grid, hipStream_t st) {
+  static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in
+  if (!attr_set) { set_lds(tblock_tail_kernel<DT, OP, NS, FU>, TAIL_LDS); attr_set = true; }
+  hipLaunchKernelGGL((tblock_tail_kernel<DT, OP, NS, FU>), grid, dim3(256), TAIL_LDS, st, p);
+}
+template <int DT>
+void dispatch_head(const cv_tblock_params& p, dim3 grid, hipStream_t st) {
+  const int ns = ring_slots(); const bool fu = full_unroll();
+  if constexpr (DT == CV_F16) {   // timing-only ablation builds (wrong results): CV_TBLOCK_ABL=1|2|3
+    static const int abl = env_int("CV_TBLOCK_ABL", 0);
+    if (abl == 1) { hipLaunchKernelGGL((tblock_head_kernel<DT, 6, true, 1>), grid, dim3(256), 32768, st, p); return; }
+    if (abl == 2) { hipLaunchKernelGGL((tblock_head_kernel<DT, 6, true, 2>), grid, dim3(256), 32768, st, p); return; }
+    if (abl == 3) { hipLaunchKernelGGL((tblock_head_kernel<DT, 6, true, 3>), grid, dim3(256), 32768, st, p); return; }
+  }
+  if (ns == 6) { if (fu) launch_head<DT, 6, true>(p, grid, st); else launch_head<DT, 6, false>(p, grid, st); }
+  else { if (fu) launch_head<DT, 4, true>(p, grid, st); else launch_head<DT, 4, false>(p, grid, st); }
+}
+template <int DT, bool OP>
+void dispatch_tail(const cv_tblock_params& p, dim3 grid, hipStream_t st) {
+  const int ns = ring_slots(); const bool fu = full_unroll();
+  if constexpr (DT == CV_F16 && OP) {
+    static const int abl = env_int("CV_TBLOCK_ABL", 0);
+    static bool attr_set = false;
+    if (!attr_set) { set_lds(tblock_tail_kernel<DT, OP, 6, true, 1>, TAIL_LDS); set_lds(tblock_tail_kernel<DT, OP, 6, true, 2>, TAIL_LDS);
+                     set_lds(tblock_tail_kernel<DT, OP, 6, true, 3>, TAIL_LDS); attr_set = true; }
+    if (abl == 1) { hipLaunchKernelGGL((tblock_tail_kernel<DT, OP, 6, true, 1>), grid, dim3(256), TAIL_LDS, st, p); return; }
+    if (abl == 2) { hipLaunchKernelGGL((tblock_tail_kernel<DT, OP, 6, true, 2>), grid, dim3(256), TAIL_LDS, st, p); return; }
+    if (abl == 3) { hipLaunchKernelGGL((tblock_tail_kernel<DT, OP, 6, true, 3>), grid, dim3(256), TAIL_LDS, st, p); return; }
+  }
+  if (ns == 6) { if (fu) launch_tail<DT, OP, 6, true>(p, grid, st); else launch_tail<DT, OP, 6, false>(p, grid, st); }
+  else { if (fu) launch_tail<DT, OP, 4, true>(p, grid, st); else launch_tail<DT, OP, 4, false>(p, grid, st); }
+}
+
 }  // namespace
 
 extern "C" int cv_sizeof_tblock_params(void) { return (int)sizeof(cv_tblock_params); }
@@ -431,11 +581,11 @@ extern "C" int cv_tblock_head(const cv_tblock_params* pp, void* stream) {
   if (!p.g1 || !p.b1n || !p.wqkv_p || !p.qk || !p.vt) return CV_ERR_ARG;
   if ((p.ldqk & 3) || (p.vt_ld & 3) || p.vt_ld < p.T || ((uintptr_t)p.qk & 7) || ((uintptr_t)p.vt & 7) || ((uintptr_t)p.wqkv_p & 15))
     return CV_ERR_ARG;
+  if ((int64_t)p.T * p.ldqk * 2 >= (1ll << 31) || (int64_t)TB_INNER * p.vt_ld * 2 >= 0x7FFFFFF0ll) return CV_ERR_ARG;   // 32-bit buffer offsets
   dim3 grid((p.T + BM - 1) / BM, p.R);
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = 32768;
-  if (p.dtype == CV_BF16) hipLaunchKernelGGL(tblock_head_kernel<CV_BF16>, grid, dim3(256), lds, st, p);
-  else hipLaunchKernelGGL(tblock_head_kernel<CV_F16>, grid, dim3(256), lds, st, p);
+  if (p.dtype == CV_BF16) dispatch_head<CV_BF16>(p, grid, st);
+  else dispatch_head<CV_F16>(p, grid, st);
   CV_CHECK_LAUNCH();
   return CV_OK;
 }
@@ -445,28 +595,14 @@ extern "C" int cv_tblock_tail(const cv_tblock_params* pp, void* stream) {
   const cv_tblock_params p = *pp;
   if (int rc = check_common(p)) return rc;
   if (!p.g3 || !p.b3n || !p.w1_p || !p.bf1 || !p.w2_p || !p.bf2) return CV_ERR_ARG;
-  if (((uintptr_t)p.w1_p & 15) || ((uintptr_t)p.w2_p & 15)) return CV_ERR_ARG;
+  if (((uintptr_t)p.w1_p & 15) || ((uintptr_t)p.w2_p & 15) || ((uintptr_t)p.bf1 & 15)) return CV_ERR_ARG;
   if (p.out_act && ((p.ldoa & 3) || ((uintptr_t)p.out_act & 7))) return CV_ERR_ARG;
   const bool outproj = p.ao != nullptr;
   if (outproj && (!p.wo_p || !p.bo || (p.ldao & 7) || ((uintptr_t)p.ao & 15) || ((uintptr_t)p.wo_p & 15))) return CV_ERR_ARG;
   dim3 grid((p.T + BM - 1) / BM, p.R);
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = 65536 + 2048 + 4096;
-  static bool attr_set = false;
-  if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in
-    hipFuncSetAttribute((const void*)tblock_tail_kernel<CV_BF16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)tblock_tail_kernel<CV_F16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)tblock_tail_kernel<CV_BF16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)tblock_tail_kernel<CV_F16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  if (p.dtype == CV_BF16) {
-    if (outproj) hipLaunchKernelGGL((tblock_tail_kernel<CV_BF16, true>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((tblock_tail_kernel<CV_BF16, false>), grid, dim3(256), lds, st, p);
-  } else {
-    if (outproj) hipLaunchKernelGGL((tblock_tail_kernel<CV_F16, true>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((tblock_tail_kernel<CV_F16, false>), grid, dim3(256), lds, st, p);
-  }
+  if (p.dtype == CV_BF16) { if (outproj) dispatch_tail<CV_BF16, true>(p, grid, st); else dispatch_tail<CV_BF16, false>(p, grid, st); }
+  else { if (outproj) dispatch_tail<CV_F16, true>(p, grid, st); else dispatch_tail<CV_F16, false>(p, grid, st); }
   CV_CHECK_LAUNCH();
   return CV_OK;
 }
