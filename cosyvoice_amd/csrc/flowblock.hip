@@ -17,10 +17,12 @@
 //     64 rows (64 flop per weight byte instead of 32 per operand byte) and never touches LDS;
 //   * a register ring of NS slots (8 fragments = 32 MFMA-steps of work each) keeps NS - 1 fragment groups in flight behind
 //     the MFMAs.  First version: 2 slots at two waves per SIMD -> one group (512 cycles) of cover against a loaded L2
-//     latency of 1-2 us, the kernels ran latency-bound (42 / 48 us per call at batch 8).  Now NS = 6 slots at ONE wave per
-//     SIMD: the MFMA accumulators move to the AGPR half of the 512-register file, which leaves the 256 architectural
-//     VGPRs to the ring (192), the operand fragments and addressing; 5 groups = 2 500 cycles of cover, 160 KB in flight
-//     per CU.  (hipcc does not place load destinations in AGPRs: an 8-slot ring was spilled to scratch inside the loop.)
+//     latency of 1-2 us.  Deeper rings at ONE wave per SIMD (6 slots in the 256 architectural VGPRs, accumulators in AGPRs;
+//     hipcc does not place load destinations in AGPRs, an 8-slot ring was spilled inside the loop) measured no faster: with a
+//     single wave per SIMD every latency of the chain is exposed (SQ counters: 25 % MFMA-busy, 35 % issue stalls, 40 % issuing;
+//     ablations: output stores 10 of the head's 28 us, GELU 7 of the tail's 40 us).  So a workgroup is now EIGHT waves on the
+//     same 64 rows (two per SIMD, the output columns split eight ways, 4 slots = 24 KiB in flight per wave): one wave's MFMAs
+//     run under the other's GELU / stores / waits, at the same L2 -> CU traffic;
 //   * the 1024-wide GELU intermediate never leaves the CU (128-column chunks through a double-buffered LDS tile),
 //     the residual row stays in the accumulators from the out-projection to the final store, and LayerNorm(norm3)
 //     is computed from those accumulators (cross-wave row statistics through 2 KiB of LDS).
@@ -38,7 +40,10 @@ namespace {
 
 constexpr int TB_C = 256, TB_INNER = 512, TB_FF = 1024;
 constexpr int BM = 64;        // rows per workgroup (4 MFMA row tiles)
-constexpr int HC = 128;       // hidden columns per FFN chunk
+constexpr int NW = 8;         // waves per workgroup (two per SIMD)
+constexpr int NTHR = 64 * NW;
+constexpr int NS = 4;         // ring slots per wave, 8 fragments (8 KiB per wave) each
+constexpr int HC = 32 * NW;   // hidden columns per FFN chunk: two 16-column tiles per wave
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
@@ -61,9 +66,21 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return fmaf(-0.5f * ax, erfc_abs, fmaxf(x, 0.f));
 }
 
-#define PIN16(v)                                                                                                      \
-  asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), \
-               "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]))
+// One weight fragment (1 KiB per wave: lane l reads bytes [16 l, 16 l + 16)) through a buffer descriptor: the fragment's byte
+// offset is wave-uniform and travels in an SGPR (soffset), the only address VGPR is 16 * lane.  With plain pointers hipcc
+// materialises a 64-bit VGPR address pair per 4 KiB of fragment offsets and hoists all of them to the kernel's top (the fully
+// unrolled head kernel carried ~100 address registers and spilled its prefetch ring to scratch).
+__device__ __forceinline__ uint4 frag_load(const __amdgpu_buffer_rsrc_t rs, int lane16, int frag) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, frag * 1024, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t frag_rsrc(const void* base, int nfrag) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, nfrag * 1024, 0x00020000);
+}
+
+// "redefine" 8 registers at this point: every load that fills them has to be issued before it (hipcc otherwise sinks each
+// load of a batch to its own consumer and pays one dependent L2 round trip per row)
+#define PIN8(v) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]))
 
 template <int DT>
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
@@ -80,17 +97,19 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 // LayerNorm of this workgroup's 64 rows straight from global memory into the K = 256 operand image (512-byte rows):
-// wave w normalises rows 16 w .. 16 w + 15, four rows per pass, 16 lanes per row (lane sub = l & 15 holds columns
+// wave w normalises rows 8 w .. 8 w + 7, four rows per pass, 16 lanes per row (lane sub = l & 15 holds columns
 // 64 k + 4 sub ..+3, k < 4: 256-byte coalesced segments), two-pass in registers, row sums by DPP.
 // Rows beyond T re-read row T-1 (finite values; their results are never stored).
 template <int DT>
 __device__ __forceinline__ void ln_rows_to_lds(const float* xs, int ldx, int t0, int T, const float* gamma, const float* beta,
                                                float eps, char* img, int wid, int lane) {
+  constexpr int RPW = BM / NW, NP = RPW / 4;   // 8 rows per wave, 2 passes
+  static_assert(NP * 4 == 8, "PIN8 covers two passes");
   const int sub = lane & 15, rr = lane >> 4;
-  f32x4_t v[16];   // [pass][k]
+  f32x4_t v[NP * 4];   // [pass][k]
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) {
-    const int t = min(t0 + wid * 16 + ps * 4 + rr, T - 1);
+  for (int ps = 0; ps < NP; ++ps) {
+    const int t = min(t0 + wid * RPW + ps * 4 + rr, T - 1);
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[ps * 4 + k] = *(const f32x4_t*)(xs + (int64_t)t * ldx + 64 * k + 4 * sub);
   }
@@ -100,11 +119,9 @@ __device__ __forceinline__ void ln_rows_to_lds(const float* xs, int ldx, int t0,
     g4[k] = *(const float4*)(gamma + 64 * k + 4 * sub);
     b4[k] = *(const float4*)(beta + 64 * k + 4 * sub);
   }
-  // all 16 row loads in flight before the first reduction: hipcc otherwise sinks every load to its row's arithmetic and pays
-  // 16 dependent L2 round trips.  The empty statement "redefines" the 16 registers, so every load has to precede it.
-  PIN16(v);
+  PIN8(v);
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) {
+  for (int ps = 0; ps < NP; ++ps) {
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) s += (v[ps * 4 + k][0] + v[ps * 4 + k][1]) + (v[ps * 4 + k][2] + v[ps * 4 + k][3]);
@@ -115,7 +132,7 @@ __device__ __forceinline__ void ln_rows_to_lds(const float* xs, int ldx, int t0,
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const float d = v[ps * 4 + k][e] - mean; v[ps * 4 + k][e] = d; q += d * d; }
     const float rstd = rsqrtf(row16_sum(q) * (1.0f / TB_C) + eps);
-    const int row = wid * 16 + ps * 4 + rr;
+    const int row = wid * RPW + ps * 4 + rr;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       *(uint2*)(img + row * 512 + (swz16(row, 8 * k + (sub >> 1)) << 4) + ((sub & 1) << 3)) =
@@ -127,41 +144,39 @@ __device__ __forceinline__ void ln_rows_to_lds(const float* xs, int ldx, int t0,
 // ============================================================================================== head: LN -> Q | K | V^T
 // Output columns: 1536 = 96 MFMA tiles (0..63 = [Q | K] row-major, 64..95 = V, stored transposed).  A wave-step is 4
 // consecutive tiles x all 8 k-steps x the 4 row tiles (128 MFMAs = 4 fragment groups of 2 k-steps); wave w takes tile
-// groups w, w + 4, ... (6 steps).  V steps swap the MFMA operands (D = xn . Wv^T has the frame index in the registers),
+// groups w, w + 8, w + 16 (3 steps).  V steps swap the MFMA operands (D = xn . Wv^T has the frame index in the registers),
 // so a lane holds 4 consecutive frames of one (head, channel) row of V^T: 8-byte stores, no transposing pass.
-constexpr int ring_body(int ns) { return ns == 4 ? 1 : (ns == 6 ? 3 : (ns == 8 ? 2 : 0)); }   // lcm(NS, 4) / 4 steps or chunks
-
-template <int DT, int NS, bool FULLU, int ABL = 0>   // ABL: timing-only ablations (1: no output stores, 2: no ring refills)
-__global__ __launch_bounds__(256, 1) void tblock_head_kernel(const cv_tblock_params p) {
+// Fragment group G = 4 step + k-quarter lives in ring slot G % 4 = k-quarter and is refilled with group G + 4 once computed.
+template <int DT, int ABL = 0>   // ABL: timing-only ablations (1: no output stores, 2: no ring refills)
+__global__ __launch_bounds__(NTHR, 2) void tblock_head_kernel(const cv_tblock_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lq = lane & 15, lg = lane >> 4;
   const int r = blockIdx.y, t0 = blockIdx.x * BM;
   const float* xs = p.x + (int64_t)r * p.T * p.ldx;
-  constexpr int NKS = TB_C / 32;                  // 8 k-steps
-  constexpr int NSTEP = 3 * TB_INNER / 16 / 16;   // 96 tiles / (4 waves x 4 tiles) = 6
-  constexpr int SPB = ring_body(NS);              // steps per loop body: group G = 4 step + k-quarter lives in slot G % NS
-  static_assert(SPB > 0 && NSTEP % SPB == 0, "ring depth must divide the group count");
+  constexpr int NKS = TB_C / 32;                       // 8 k-steps
+  constexpr int NSTEP = 3 * TB_INNER / 16 / (4 * NW);  // 96 tiles / (8 waves x 4 tiles) = 3
 
-  const uint4* Wl = (const uint4*)p.wqkv_p + lane;
+  const __amdgpu_buffer_rsrc_t w_rs = frag_rsrc(p.wqkv_p, 96 * NKS);
+  const int lane16 = lane * 16;
   uint4 s[NS][8];
-  // fragment group G (clamped to the last step: harmless re-reads at the end): tiles (4 step + w) * 4 + j, k-steps 2 kq + u
+  // fragment group G (clamped to the last step: harmless re-reads at the end): tiles (step * NW + w) * 4 + j, k-steps 2 kq + u
   auto ld = [&](uint4 (&sl)[8], int G) {
     if ((ABL & 2) && G >= NS) return;
     const int st = min(G >> 2, NSTEP - 1), kq = G & 3;
-    const int tile0 = (st * 4 + wid) * 4;
+    const int tile0 = (st * NW + wid) * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) sl[j * 2 + u] = Wl[((tile0 + j) * NKS + kq * 2 + u) * 64];
+      for (int u = 0; u < 2; ++u) sl[j * 2 + u] = frag_load(w_rs, lane16, (tile0 + j) * NKS + kq * 2 + u);
     __builtin_amdgcn_sched_barrier(0);   // ring refills stay where they are written: NS - 1 fragment groups ahead of their use
   };
-#pragma unroll
-  for (int g = 0; g < NS / 2; ++g) ld(s[g], g);          // half of the ring flies during the LayerNorm (register budget)
+  ld(s[0], 0);
+  ld(s[1], 1);
   ln_rows_to_lds<DT>(xs, p.ldx, t0, p.T, p.g1, p.b1n, p.eps, smem, wid, lane);
-#pragma unroll
-  for (int g = NS / 2; g < NS; ++g) ld(s[g], g);
+  ld(s[2], 2);
+  ld(s[3], 3);
   __syncthreads();
 
   f32x4_t acc[4][4];
@@ -189,62 +204,59 @@ __global__ __launch_bounds__(256, 1) void tblock_head_kernel(const cv_tblock_par
       (void*)((uint16_t*)p.vt + (int64_t)r * TB_INNER * p.vt_ld), 0, TB_INNER * p.vt_ld * 2, 0x00020000);
   const bool t_mod4 = (p.T & 3) != 0;
 
-  // fully unrolled (6 steps): across a loop back-edge hipcc merges the pending-load state of the entry edge (ring drained or
-  // not) with the steady state and falls back to conservative vmcnt values that drain most of the ring once per iteration
-#pragma unroll(FULLU ? 8 : 1)
-  for (int st0 = 0; st0 < NSTEP; st0 += SPB) {
+  // fully unrolled (3 steps): across a loop back-edge hipcc merges the pending-load state of the entry edge with the steady
+  // state and falls back to conservative vmcnt values that drain most of the ring once per iteration
 #pragma unroll
-    for (int ss = 0; ss < SPB; ++ss) {
-      const int st = st0 + ss;
-      const int tile0 = (st * 4 + wid) * 4;
-      const bool vpart = tile0 >= (2 * TB_INNER) / 16;               // wave-uniform
+  for (int st = 0; st < NSTEP; ++st) {
+    const int tile0 = (st * NW + wid) * 4;
+    constexpr int QK_STEPS = (2 * TB_INNER / 16) / (4 * NW);   // steps 0, 1: [Q | K] tiles for every wave; step 2: V tiles
+    const bool vpart = st >= QK_STEPS;                         // compile-time after unrolling
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      if (!vpart) {
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (!vpart) {
 #pragma unroll
-        for (int kq = 0; kq < 4; ++kq) { compute(s[(ss * 4 + kq) % NS], kq, false); ld(s[(ss * 4 + kq) % NS], st * 4 + kq + NS); }
-        // D rows = output column: lane holds row m = 16 i + lq, columns n .. n + 3
+      for (int kq = 0; kq < 4; ++kq) { compute(s[kq], kq, false); ld(s[kq], st * 4 + kq + NS); }
+      // D rows = output column: lane holds row m = 16 i + lq, columns n .. n + 3
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int t = t0 + 16 * i + lq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint2 u = pack4<DT>(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+          if (ABL & 1) { asm volatile("" :: "v"(u.x), "v"(u.y)); continue; }
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{u.x, u.y}, qk_rs, (t * p.ldqk + (tile0 + j) * 16 + 4 * lg) * 2, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) { compute(s[kq], kq, true); ld(s[kq], st * 4 + kq + NS); }
+      // D rows = frame: lane holds V^T row (head * 64 + d) = column tile * 16 + lq, frames t .. t + 3
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int vrow = (tile0 + j) * 16 + lq - 2 * TB_INNER;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int t = t0 + 16 * i + lq;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const uint2 u = pack4<DT>(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-            if (ABL & 1) { asm volatile("" :: "v"(u.x), "v"(u.y)); continue; }
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{u.x, u.y}, qk_rs, (t * p.ldqk + (tile0 + j) * 16 + 4 * lg) * 2, 0, 0);
-          }
+          const int t = t0 + 16 * i + 4 * lg;
+          const uint2 u = pack4<DT>(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+          const int off = (vrow * p.vt_ld + t) * 2;
+          if (ABL & 1) { asm volatile("" :: "v"(u.x), "v"(u.y)); continue; }
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{u.x, u.y}, vt_rs, (t + 3 < p.T) ? off : 0x7FFFFFF0, 0, 0);
         }
-      } else {
-#pragma unroll
-        for (int kq = 0; kq < 4; ++kq) { compute(s[(ss * 4 + kq) % NS], kq, true); ld(s[(ss * 4 + kq) % NS], st * 4 + kq + NS); }
-        // D rows = frame: lane holds V^T row (head * 64 + d) = column tile * 16 + lq, frames t .. t + 3
+      }
+      if (t_mod4) {   // T not a multiple of 4 (the v1 flow's odd lengths): the group that straddles T, element by element
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int vrow = (tile0 + j) * 16 + lq - 2 * TB_INNER;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int t = t0 + 16 * i + 4 * lg;
-            const uint2 u = pack4<DT>(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-            const int off = (vrow * p.vt_ld + t) * 2;
-            if (ABL & 1) { asm volatile("" :: "v"(u.x), "v"(u.y)); continue; }
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{u.x, u.y}, vt_rs, (t + 3 < p.T) ? off : 0x7FFFFFF0, 0, 0);
-          }
-        }
-        if (t_mod4) {   // T not a multiple of 4 (the v1 flow's odd lengths): the group that straddles T, element by element
+            const bool straddle = (t < p.T) && (t + 3 >= p.T);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int vrow = (tile0 + j) * 16 + lq - 2 * TB_INNER;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int t = t0 + 16 * i + 4 * lg;
-              const bool straddle = (t < p.T) && (t + 3 >= p.T);
-#pragma unroll
-              for (int e = 0; e < 3; ++e)
-                __builtin_amdgcn_raw_buffer_store_b16((short)Elem16<DT>::from_f32(acc[i][j][e]), vt_rs,
-                                                      (straddle && t + e < p.T) ? (vrow * p.vt_ld + t + e) * 2 : 0x7FFFFFF0, 0, 0);
-            }
+            for (int e = 0; e < 3; ++e)
+              __builtin_amdgcn_raw_buffer_store_b16((short)Elem16<DT>::from_f32(acc[i][j][e]), vt_rs,
+                                                    (straddle && t + e < p.T) ? (vrow * p.vt_ld + t + e) * 2 : 0x7FFFFFF0, 0, 0);
           }
         }
       }
@@ -253,128 +265,120 @@ __global__ __launch_bounds__(256, 1) void tblock_head_kernel(const cv_tblock_par
 }
 
 // ============================================================================================== tail: to_out + LN + FFN
-// LDS: [0, 64 K) attention-output image (64 rows x 1024 B) during the out-projection, afterwards xn image (64 x 512 B) at 0
-// and the two GELU chunk tiles (64 x 256 B each) at 32 K / 48 K; [64 K, 66 K) cross-wave row statistics; [66 K, 70 K) bf1; [70 K, 74 K) bo, g3, b3n, bf2.
-// Wave w owns output columns [64 w, 64 w + 64) of the 256-wide residual row for the whole kernel (acc2: 4 x 4 tiles).
-// Fragment-group sequence of a wave: 8 out-projection groups (4 tiles x 2 k-steps), then per 128-column hidden chunk c the
-// groups q = 0, 1 (hidden layer: 2 tiles x k-steps 4 q ..+3) and q = 2, 3 (output layer: 4 tiles x k-steps 4 c + 2 (q - 2) ..+1);
-// The wave's groups are numbered through (out-projection 0..7 when present, then FFN group f = 4 c + q); group G lives in ring
-// slot G % NS and, once computed, its slot is refilled with group G + NS.
-template <int DT, bool OUTPROJ, int NS, bool FULLU, int ABL = 0>   // ABL: timing-only ablations (1: GELU -> identity, 2: no ring refills)
-__global__ __launch_bounds__(256, 1) void tblock_tail_kernel(const cv_tblock_params p) {
+// LDS: [0, 64 K) attention-output image (64 rows x 1024 B) during the out-projection, afterwards the xn image (64 x 512 B) at 0
+// and the first GELU chunk tile (64 x 512 B) at 32 K; [64 K, 96 K) second GELU chunk tile; [96 K, 100 K) cross-wave row
+// statistics; [100 K, 104 K) bf1; [104 K, 108 K) bo, g3, b3n, bf2.
+// Wave w owns output columns [32 w, 32 w + 32) of the 256-wide residual row for the whole kernel (acc2: 4 x 2 tiles) and hidden
+// columns [32 w, 32 w + 32) of every 256-column FFN chunk (acc1: 4 x 2 tiles).  Every fragment group is 2 tiles x 4 k-steps
+// (32 MFMAs): 4 out-projection groups (k-steps 4 g ..+3 of 16), then per chunk c the groups q = 0, 1 (hidden layer, k-steps
+// 4 q ..+3 of 8) and q = 2, 3 (output layer, k-steps 8 c + 4 (q - 2) ..+3 of 32).  Group G lives in ring slot G % 4 and its slot
+// is refilled with group G + 4 once computed.
+template <int DT, bool OUTPROJ, int ABL = 0>   // ABL: timing-only ablations (1: GELU -> identity, 2: no ring refills)
+__global__ __launch_bounds__(NTHR, 2) void tblock_tail_kernel(const cv_tblock_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ximg = smem;
-  char* himg = smem + 32768;
-  float* red = (float*)(smem + 65536);   // [2][4 waves][64 rows]
-  const float* b1s = (const float*)(smem + 65536 + 2048);   // hidden-layer bias, staged once (a global load inside the chunk loop
-                                                            // is sunk by hipcc to its use and drains the weight prefetch: vmcnt(0))
+  char* himg0 = smem + 32768;
+  char* himg1 = smem + 65536;
+  float* red = (float*)(smem + 98304);                // [2][8 waves][64 rows]
+  const float* b1s = (const float*)(smem + 102400);   // hidden-layer bias, staged once (a global load inside the chunk loop
+                                                      // is sunk by hipcc to its use and drains the weight prefetch: vmcnt(0))
+  float* vecs = (float*)(smem + 106496);              // [4][256]: bo | g3 | b3n | bf2, likewise
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lq = lane & 15, lg = lane >> 4;
   const int r = blockIdx.y, t0 = blockIdx.x * BM;
   float* xs = p.x + (int64_t)r * p.T * p.ldx;
-  const int ncol0 = wid * 64;
-  constexpr int NC = TB_FF / HC;        // 8 chunks
-  constexpr int CPB = ring_body(NS);    // chunks per loop body (slot indices repeat every lcm(NS, 4) groups)
-  constexpr int GOFF = OUTPROJ ? 8 : 0; // number of the first FFN group
-  static_assert(CPB > 0, "unsupported ring depth");
-  ((float4*)(smem + 65536 + 2048))[tid] = ((const float4*)p.bf1)[tid];   // 1024 floats; visible after the first barrier
-  // the 256-wide vectors of the middle of the kernel (to_out bias, norm3 weight / bias, output bias) likewise: loaded here, ahead
-  // of the weight ring in the in-order vmcnt queue, read back from LDS where they are needed
-  float* vecs = (float*)(smem + 65536 + 2048 + 4096);   // [4][256]: bo | g3 | b3n | bf2
-  vecs[tid] = OUTPROJ ? p.bo[tid] : 0.f;
-  vecs[256 + tid] = p.g3[tid];
-  vecs[512 + tid] = p.b3n[tid];
-  vecs[768 + tid] = p.bf2[tid];
+  const int ncol0 = wid * 32;
+  constexpr int NC = TB_FF / HC;   // 4 chunks
+  if (tid < 256) ((float4*)(smem + 102400))[tid] = ((const float4*)p.bf1)[tid];   // 1024 floats; visible after the first barrier
+  vecs[tid] = tid < 256 ? (OUTPROJ ? p.bo[tid] : 0.f) : p.g3[tid - 256];
+  vecs[512 + tid] = tid < 256 ? p.b3n[tid] : p.bf2[tid - 256];
 
-  const uint4* W1l = (const uint4*)p.w1_p + lane;   // [64 tiles][8 ks]
-  const uint4* W2l = (const uint4*)p.w2_p + lane;   // [16 tiles][32 ks]
+  const __amdgpu_buffer_rsrc_t w1_rs = frag_rsrc(p.w1_p, 64 * 8);    // [64 tiles][8 ks]
+  const __amdgpu_buffer_rsrc_t w2_rs = frag_rsrc(p.w2_p, 16 * 32);   // [16 tiles][32 ks]
+  const int lane16 = lane * 16;
   uint4 s[NS][8];
   auto ld_ffn = [&](uint4 (&sl)[8], int f) {   // FFN group f = 4 c + q (clamped to the last chunk: harmless re-reads at the end)
     if ((ABL & 2) && f >= NS) return;
     const int c = min(f >> 2, NC - 1), q = f & 3;
-    if (q < 2) {   // hidden tiles 8 c + 2 w + j (j < 2), k-steps 4 q + u (u < 4): sl[j * 4 + u]
+    if (q < 2) {   // hidden tiles 16 c + 2 w + j, k-steps 4 q + u
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) sl[j * 4 + u] = W1l[((8 * c + 2 * wid + j) * (TB_C / 32) + 4 * q + u) * 64];
-    } else {       // output tiles 4 w + j (j < 4), k-steps 4 c + 2 (q - 2) + u (u < 2): sl[j * 2 + u]
+        for (int u = 0; u < 4; ++u) sl[j * 4 + u] = frag_load(w1_rs, lane16, (16 * c + 2 * wid + j) * (TB_C / 32) + 4 * q + u);
+    } else {       // output tiles 2 w + j, k-steps 8 c + 4 (q - 2) + u
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) sl[j * 2 + u] = W2l[((4 * wid + j) * (TB_FF / 32) + 4 * c + 2 * (q - 2) + u) * 64];
+        for (int u = 0; u < 4; ++u) sl[j * 4 + u] = frag_load(w2_rs, lane16, (2 * wid + j) * (TB_FF / 32) + 8 * c + 4 * (q - 2) + u);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
 
   // residual rows in the accumulator layout (row 16 i + lq, columns ncol0 + 16 j + 4 lg ..+3)
-  f32x4_t acc2[4][4];
+  f32x4_t acc2[4][2];
   auto load_residual = [&]() {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int t = min(t0 + 16 * i + lq, p.T - 1);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc2[i][j] = *(const f32x4_t*)(xs + (int64_t)t * p.ldx + ncol0 + 16 * j + 4 * lg);
+      for (int j = 0; j < 2; ++j) acc2[i][j] = *(const f32x4_t*)(xs + (int64_t)t * p.ldx + ncol0 + 16 * j + 4 * lg);
     }
   };
 
   if constexpr (OUTPROJ) {
     const uint16_t* aos = (const uint16_t*)p.ao + (int64_t)r * p.T * p.ldao;
-    const uint4* Wol = (const uint4*)p.wo_p + lane;   // [16 tiles][16 ks]
-    auto ld_o = [&](uint4 (&sl)[8], int g) {          // group g: tiles 4 w + j, k-steps 2 g + u
+    const __amdgpu_buffer_rsrc_t wo_rs = frag_rsrc(p.wo_p, 16 * 16);   // [16 tiles][16 ks]
+    auto ld_o = [&](uint4 (&sl)[8], int g) {          // group g: tiles 2 w + j, k-steps 4 g + u
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) sl[j * 2 + u] = Wol[((4 * wid + j) * (TB_INNER / 32) + 2 * g + u) * 64];
+        for (int u = 0; u < 4; ++u) sl[j * 4 + u] = frag_load(wo_rs, lane16, (2 * wid + j) * (TB_INNER / 32) + 4 * g + u);
       __builtin_amdgcn_sched_barrier(0);
     };
     {
-      // ---- attention output tile -> LDS operand image (1024-byte rows), one row per wave-instruction
-      u32x4_t v[16];
+      // ---- attention output tile -> LDS operand image (1024-byte rows), one row per wave-instruction, 8 rows per wave
+      u32x4_t v[8];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int t = min(t0 + wid * 16 + i, p.T - 1);
+      for (int i = 0; i < 8; ++i) {
+        const int t = min(t0 + wid * 8 + i, p.T - 1);
         v[i] = *(const u32x4_t*)(aos + (int64_t)t * p.ldao + lane * 8);
       }
       __builtin_amdgcn_sched_barrier(0);
+      ld_o(s[0], 0);
+      ld_o(s[1], 1);
+      PIN8(v);
 #pragma unroll
-      for (int g = 0; g < NS / 2; ++g) ld_o(s[g], g);   // half of the ring behind the tile loads (register budget), the rest below
-      PIN16(v);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = wid * 16 + i;
+      for (int i = 0; i < 8; ++i) {
+        const int row = wid * 8 + i;
         *(u32x4_t*)(smem + row * 1024 + (swz16(row, lane) << 4)) = v[i];
       }
     }
-#pragma unroll
-    for (int g = NS / 2; g < NS; ++g) ld_o(s[g], g);
+    ld_o(s[2], 2);
+    ld_o(s[3], 3);
     load_residual();
     __syncthreads();
     auto compute_o = [&](uint4 (&sl)[8], int g) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int ks = 2 * g + u;
+      for (int u = 0; u < 4; ++u) {
+        const int ks = 4 * g + u;
         uint4 a[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = *(const uint4*)(smem + (16 * i + lq) * 1024 + (swz16(lq, ks * 4 + lg) << 4));
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc2[i][j] = mfma_block<DT>(sl[j * 2 + u], a[i], acc2[i][j]);
+          for (int i = 0; i < 4; ++i) acc2[i][j] = mfma_block<DT>(sl[j * 4 + u], a[i], acc2[i][j]);
       }
       __builtin_amdgcn_sched_barrier(0);
     };
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      compute_o(s[g % NS], g);
-      if (g + NS < 8) ld_o(s[g % NS], g + NS);
-      else ld_ffn(s[g % NS], g + NS - 8);   // the first FFN groups fly during the LayerNorm
-    }
+    for (int g = 0; g < 4; ++g) { compute_o(s[g], g); ld_ffn(s[g], g); }   // the first FFN groups fly during the LayerNorm
 
     // ---- + to_out bias: acc2 is now the block's first residual output x1; LayerNorm(norm3) from the accumulators
-    float4 gam[4], bet[4];
+    float4 gam[2], bet[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2; ++j) {
       const int n = ncol0 + 16 * j + 4 * lg;
       const float4 bo = *(const float4*)(vecs + n);
       gam[j] = *(const float4*)(vecs + 256 + n);
@@ -382,12 +386,12 @@ __global__ __launch_bounds__(256, 1) void tblock_tail_kernel(const cv_tblock_par
 #pragma unroll
       for (int i = 0; i < 4; ++i) { acc2[i][j][0] += bo.x; acc2[i][j][1] += bo.y; acc2[i][j][2] += bo.z; acc2[i][j][3] += bo.w; }
     }
-    float mean[4], rstd[4];
+    float mean[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float sm = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) sm += (acc2[i][j][0] + acc2[i][j][1]) + (acc2[i][j][2] + acc2[i][j][3]);
+      for (int j = 0; j < 2; ++j) sm += (acc2[i][j][0] + acc2[i][j][1]) + (acc2[i][j][2] + acc2[i][j][3]);
       sm += __shfl_xor(sm, 16, 64);
       sm += __shfl_xor(sm, 32, 64);
       if (lg == 0) red[wid * 64 + 16 * i + lq] = sm;
@@ -396,108 +400,109 @@ __global__ __launch_bounds__(256, 1) void tblock_tail_kernel(const cv_tblock_par
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = 16 * i + lq;
-      mean[i] = ((red[m] + red[64 + m]) + (red[128 + m] + red[192 + m])) * (1.0f / TB_C);
+      float sm = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) sm += red[w * 64 + m];
+      mean[i] = sm * (1.0f / TB_C);
       float q = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const float d = acc2[i][j][e] - mean[i]; q += d * d; }
       q += __shfl_xor(q, 16, 64);
       q += __shfl_xor(q, 32, 64);
-      if (lg == 0) red[256 + wid * 64 + m] = q;
+      if (lg == 0) red[NW * 64 + wid * 64 + m] = q;
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = 16 * i + lq;
-      rstd[i] = rsqrtf(((red[256 + m] + red[320 + m]) + (red[384 + m] + red[448 + m])) * (1.0f / TB_C) + p.eps);
+      float qs = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int w = 0; w < NW; ++w) qs += red[NW * 64 + w * 64 + m];
+      const float sc = rsqrtf(qs * (1.0f / TB_C) + p.eps);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
         const int n = ncol0 + 16 * j + 4 * lg;   // 4 consecutive columns = half of 16-byte chunk n >> 3
-        const float sc = rstd[i];
         *(uint2*)(ximg + m * 512 + (swz16(m, n >> 3) << 4) + ((lg & 1) << 3)) =
             pack4<DT>((acc2[i][j][0] - mean[i]) * sc * gam[j].x + bet[j].x, (acc2[i][j][1] - mean[i]) * sc * gam[j].y + bet[j].y,
                       (acc2[i][j][2] - mean[i]) * sc * gam[j].z + bet[j].z, (acc2[i][j][3] - mean[i]) * sc * gam[j].w + bet[j].w);
       }
     }
   } else {
-#pragma unroll
-    for (int f = 0; f < NS / 2; ++f) ld_ffn(s[f], f);
+    ld_ffn(s[0], 0);
+    ld_ffn(s[1], 1);
     ln_rows_to_lds<DT>(xs, p.ldx, t0, p.T, p.g3, p.b3n, p.eps, ximg, wid, lane);
-#pragma unroll
-    for (int f = NS / 2; f < NS; ++f) ld_ffn(s[f], f);
+    ld_ffn(s[2], 2);
+    ld_ffn(s[3], 3);
     load_residual();
+    __syncthreads();   // vecs staged
   }
   // + FFN output bias: the accumulators then collect x1 + b2 + sum_c gelu(..) . W2_c^T
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < 2; ++j) {
     const float4 b2 = *(const float4*)(vecs + 768 + ncol0 + 16 * j + 4 * lg);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { acc2[i][j][0] += b2.x; acc2[i][j][1] += b2.y; acc2[i][j][2] += b2.z; acc2[i][j][3] += b2.w; }
   }
   __syncthreads();   // xn image complete
 
-#pragma unroll(FULLU ? 8 : 1)   // no loop back-edge: exact vmcnt bookkeeping for the ring (see the head kernel)
-  for (int c0 = 0; c0 < NC; c0 += CPB) {
+#pragma unroll   // 4 chunks, no loop back-edge: exact vmcnt bookkeeping for the ring (see the head kernel)
+  for (int c = 0; c < NC; ++c) {
+    char* hb = (c & 1) ? himg1 : himg0;
+    // the accumulators of the hidden layer start from its bias (this wave's two tiles of the chunk)
+    f32x4_t acc1[4][2];
 #pragma unroll
-    for (int cc = 0; cc < CPB; ++cc) {
-      const int c = c0 + cc;
-      if (c >= NC) break;                    // uniform (NC is not a multiple of a 3-chunk body)
-      char* hb = himg + (c & 1) * 16384;
-      // the accumulators of the hidden layer start from its bias (this wave's two tiles of the chunk)
-      f32x4_t acc1[4][2];
+    for (int j = 0; j < 2; ++j) {
+      const float4 b1v = *(const float4*)(b1s + c * HC + (2 * wid + j) * 16 + 4 * lg);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc1[i][j] = f32x4_t{b1v.x, b1v.y, b1v.z, b1v.w};
+    }
+    auto compute_g1 = [&](uint4 (&sl)[8], int hf) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ks = 4 * hf + u;
+        uint4 a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *(const uint4*)(ximg + (16 * i + lq) * 512 + (swz16(lq, ks * 4 + lg) << 4));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc1[i][j] = mfma_block<DT>(sl[j * 4 + u], a[i], acc1[i][j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto compute_g2 = [&](uint4 (&sl)[8], int hf) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ks = 4 * hf + u;   // k-step inside the chunk (8 x 32 = 256 hidden columns)
+        uint4 a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *(const uint4*)(hb + (16 * i + lq) * 512 + (swz16(lq, ks * 4 + lg) << 4));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc2[i][j] = mfma_block<DT>(sl[j * 4 + u], a[i], acc2[i][j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    compute_g1(s[0], 0); ld_ffn(s[0], 4 * c + 0 + NS);
+    compute_g1(s[1], 1); ld_ffn(s[1], 4 * c + 1 + NS);
+    // GELU -> 16-bit chunk tile (row 16 i + lq, hidden columns (2 w + j) * 16 + 4 lg ..+3 of the chunk)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = 16 * i + lq;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const float4 b1v = *(const float4*)(b1s + c * HC + (2 * wid + j) * 16 + 4 * lg);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc1[i][j] = f32x4_t{b1v.x, b1v.y, b1v.z, b1v.w};
+        const int ch = (2 * wid + j) * 2 + (lg >> 1);
+        *(uint2*)(hb + m * 512 + (swz16(m, ch) << 4) + ((lg & 1) << 3)) =
+            (ABL & 1) ? pack4<DT>(acc1[i][j][0], acc1[i][j][1], acc1[i][j][2], acc1[i][j][3]) :
+            pack4<DT>(gelu_erf(acc1[i][j][0]), gelu_erf(acc1[i][j][1]), gelu_erf(acc1[i][j][2]), gelu_erf(acc1[i][j][3]));
       }
-      auto compute_g1 = [&](uint4 (&sl)[8], int hf) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int ks = 4 * hf + u;
-          uint4 a[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) a[i] = *(const uint4*)(ximg + (16 * i + lq) * 512 + (swz16(lq, ks * 4 + lg) << 4));
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc1[i][j] = mfma_block<DT>(sl[j * 4 + u], a[i], acc1[i][j]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      auto compute_g2 = [&](uint4 (&sl)[8], int hf) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int ks = 2 * hf + u;   // k-step inside the chunk (4 x 32 = 128 hidden columns)
-          uint4 a[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) a[i] = *(const uint4*)(hb + (16 * i + lq) * 256 + (swz16(lq, ks * 4 + lg) << 4));
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc2[i][j] = mfma_block<DT>(sl[j * 2 + u], a[i], acc2[i][j]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      compute_g1(s[(GOFF + cc * 4 + 0) % NS], 0); ld_ffn(s[(GOFF + cc * 4 + 0) % NS], 4 * c + 0 + NS);
-      compute_g1(s[(GOFF + cc * 4 + 1) % NS], 1); ld_ffn(s[(GOFF + cc * 4 + 1) % NS], 4 * c + 1 + NS);
-      // GELU -> 16-bit chunk tile (row 16 i + lq, hidden columns (2 w + j) * 16 + 4 lg ..+3 of the chunk)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = 16 * i + lq;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int ch = (2 * wid + j) * 2 + (lg >> 1);
-          *(uint2*)(hb + m * 256 + (swz16(m, ch) << 4) + ((lg & 1) << 3)) =
-              (ABL & 1) ? pack4<DT>(acc1[i][j][0], acc1[i][j][1], acc1[i][j][2], acc1[i][j][3]) :
-              pack4<DT>(gelu_erf(acc1[i][j][0]), gelu_erf(acc1[i][j][1]), gelu_erf(acc1[i][j][2]), gelu_erf(acc1[i][j][3]));
-        }
-      }
-      __syncthreads();   // one barrier per chunk: the next chunk's GELU tile goes to the other buffer
-      compute_g2(s[(GOFF + cc * 4 + 2) % NS], 0); ld_ffn(s[(GOFF + cc * 4 + 2) % NS], 4 * c + 2 + NS);
-      compute_g2(s[(GOFF + cc * 4 + 3) % NS], 1); ld_ffn(s[(GOFF + cc * 4 + 3) % NS], 4 * c + 3 + NS);
     }
+    __syncthreads();   // one barrier per chunk: the next chunk's GELU tile goes to the other buffer
+    compute_g2(s[2], 0); ld_ffn(s[2], 4 * c + 2 + NS);
+    compute_g2(s[3], 1); ld_ffn(s[3], 4 * c + 3 + NS);
   }
 
   // ---- store the block output (fp32 residual stream, in place) + optional 16-bit copy (skip connection / next conv operand)
@@ -507,7 +512,7 @@ __global__ __launch_bounds__(256, 1) void tblock_tail_kernel(const cv_tblock_par
     const int t = t0 + 16 * i + lq;
     if (t >= p.T) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2; ++j) {
       const int n = ncol0 + 16 * j + 4 * lg;
       *(float4*)(xs + (int64_t)t * p.ldx + n) = make_float4(acc2[i][j][0], acc2[i][j][1], acc2[i][j][2], acc2[i][j][3]);
       if (oa) *(uint2*)(oa + (int64_t)t * p.ldoa + n) = pack4<DT>(acc2[i][j][0], acc2[i][j][1], acc2[i][j][2], acc2[i][j][3]);
@@ -522,52 +527,37 @@ int check_common(const cv_tblock_params& p) {
   return CV_OK;
 }
 
-// ring depth (one wave per SIMD either way): 6 slots by default; CV_TBLOCK_RING=4 selects the 4-slot form; CV_TBLOCK_UNROLL=0 keeps
-// the step / chunk loops rolled (tuning aids)
 int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-int ring_slots() { static int v = env_int("CV_TBLOCK_RING", 6) == 4 ? 4 : 6; return v; }
-bool full_unroll() { static bool v = env_int("CV_TBLOCK_UNROLL", 1) != 0; return v; }
 
 template <typename K>
 void set_lds(K kern, size_t lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
 
-template <int DT, int NS, bool FU>
-void launch_head(const cv_tblock_params& p, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL((tblock_head_kernel<DT, NS, FU>), grid, dim3(256), 32768, st, p);
-}
-constexpr size_t TAIL_LDS = 65536 + 2048 + 4096 + 4096;
-template <int DT, bool OP, int NS, bool FU>
+constexpr size_t TAIL_LDS = 98304 + 4096 + 4096 + 4096;
+template <int DT, bool OP, int ABL>
 void launch_tail(const cv_tblock_params& p, dim3 grid, hipStream_t st) {
   static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in
-  if (!attr_set) { set_lds(tblock_tail_kernel<DT, OP, NS, FU>, TAIL_LDS); attr_set = true; }
-  hipLaunchKernelGGL((tblock_tail_kernel<DT, OP, NS, FU>), grid, dim3(256), TAIL_LDS, st, p);
+  if (!attr_set) { set_lds(tblock_tail_kernel<DT, OP, ABL>, TAIL_LDS); attr_set = true; }
+  hipLaunchKernelGGL((tblock_tail_kernel<DT, OP, ABL>), grid, dim3(NTHR), TAIL_LDS, st, p);
 }
 template <int DT>
 void dispatch_head(const cv_tblock_params& p, dim3 grid, hipStream_t st) {
-  const int ns = ring_slots(); const bool fu = full_unroll();
   if constexpr (DT == CV_F16) {   // timing-only ablation builds (wrong results): CV_TBLOCK_ABL=1|2|3
     static const int abl = env_int("CV_TBLOCK_ABL", 0);
-    if (abl == 1) { hipLaunchKernelGGL((tblock_head_kernel<DT, 6, true, 1>), grid, dim3(256), 32768, st, p); return; }
-    if (abl == 2) { hipLaunchKernelGGL((tblock_head_kernel<DT, 6, true, 2>), grid, dim3(256), 32768, st, p); return; }
-    if (abl == 3) { hipLaunchKernelGGL((tblock_head_kernel<DT, 6, true, 3>), grid, dim3(256), 32768, st, p); return; }
+    if (abl == 1) { hipLaunchKernelGGL((tblock_head_kernel<DT, 1>), grid, dim3(NTHR), 32768, st, p); return; }
+    if (abl == 2) { hipLaunchKernelGGL((tblock_head_kernel<DT, 2>), grid, dim3(NTHR), 32768, st, p); return; }
+    if (abl == 3) { hipLaunchKernelGGL((tblock_head_kernel<DT, 3>), grid, dim3(NTHR), 32768, st, p); return; }
   }
-  if (ns == 6) { if (fu) launch_head<DT, 6, true>(p, grid, st); else launch_head<DT, 6, false>(p, grid, st); }
-  else { if (fu) launch_head<DT, 4, true>(p, grid, st); else launch_head<DT, 4, false>(p, grid, st); }
+  hipLaunchKernelGGL((tblock_head_kernel<DT, 0>), grid, dim3(NTHR), 32768, st, p);
 }
 template <int DT, bool OP>
 void dispatch_tail(const cv_tblock_params& p, dim3 grid, hipStream_t st) {
-  const int ns = ring_slots(); const bool fu = full_unroll();
   if constexpr (DT == CV_F16 && OP) {
     static const int abl = env_int("CV_TBLOCK_ABL", 0);
-    static bool attr_set = false;
-    if (!attr_set) { set_lds(tblock_tail_kernel<DT, OP, 6, true, 1>, TAIL_LDS); set_lds(tblock_tail_kernel<DT, OP, 6, true, 2>, TAIL_LDS);
-                     set_lds(tblock_tail_kernel<DT, OP, 6, true, 3>, TAIL_LDS); attr_set = true; }
-    if (abl == 1) { hipLaunchKernelGGL((tblock_tail_kernel<DT, OP, 6, true, 1>), grid, dim3(256), TAIL_LDS, st, p); return; }
-    if (abl == 2) { hipLaunchKernelGGL((tblock_tail_kernel<DT, OP, 6, true, 2>), grid, dim3(256), TAIL_LDS, st, p); return; }
-    if (abl == 3) { hipLaunchKernelGGL((tblock_tail_kernel<DT, OP, 6, true, 3>), grid, dim3(256), TAIL_LDS, st, p); return; }
+    if (abl == 1) { launch_tail<DT, OP, 1>(p, grid, st); return; }
+    if (abl == 2) { launch_tail<DT, OP, 2>(p, grid, st); return; }
+    if (abl == 3) { launch_tail<DT, OP, 3>(p, grid, st); return; }
   }
-  if (ns == 6) { if (fu) launch_tail<DT, OP, 6, true>(p, grid, st); else launch_tail<DT, OP, 6, false>(p, grid, st); }
-  else { if (fu) launch_tail<DT, OP, 4, true>(p, grid, st); else launch_tail<DT, OP, 4, false>(p, grid, st); }
+  launch_tail<DT, OP, 0>(p, grid, st);
 }
 
 }  // namespace
