@@ -5,18 +5,28 @@ Workload (BASELINE.json configs[3], "Full LLM->flow->hifigan pipeline, batch 8 x
 hipGraph token loop"): per GPU 8 utterances, each a 10 s prompt (N_p=250 prompt speech tokens,
 T_p=500 prompt mel frames, 10 prompt-text + 20 text ids -> prefill length 282) generating N_g=250 teacher-forced
 speech tokens = 10.0 s of 24 kHz audio; flow T = 1000 frames, 10 CFG Euler steps; HiFT 500 frames -> 240 000 samples.
-One "step" = the whole batch through the pipeline (prefill + 249 graph-replayed decode steps incl. on-device sampling,
-flow encoder + solver, HiFT, waveform D2H).  The K timed steps are software-pipelined over two HIP streams (LLM decode
-of step i+1 overlaps flow + HiFT of step i, as the reference overlaps its LLM thread with flow/HiFT); all K steps' work,
-fill and drain included, lies inside the timed region.  Synthetic inputs + key-seeded random weights of the reference's
-architecture (no checkpoint exists offline); inputs are resident in HBM before the timed region.
+One "step" = the whole batch through the pipeline (prefill + 249 decode steps incl. on-device sampling, flow encoder +
+solver, HiFT, waveform D2H).  The K timed steps are software-pipelined (LLM decode of later steps overlaps flow + HiFT of
+step i, as the reference overlaps its LLM thread with flow/HiFT); all K steps' work, fill and drain included, lies inside
+the timed region.  Synthetic inputs + key-seeded random weights of the reference's architecture (no checkpoint exists
+offline); inputs are resident in HBM before the timed region.
 
-N>1: one process per GPU (torchrun), utterances sharded 8 per rank (weak scaling), ONE RCCL broadcast per step of the
-shared prompt conditioning from rank 0; barrier + synchronize bracket the timed region, MAX over ranks.
+N>1 (BASELINE configs[4]): one process per GPU (torchrun); a GLOBAL list of 8 x N utterances is sharded round-robin
+(cosyvoice_amd.dist.shard_utterances: weak scaling, 8 per rank), ONE broadcast per step of the shared prompt conditioning
+from rank 0 (dist.pack / broadcast / unpack_conditioning; RCCL over xGMI), no other collective on the data
+path; barrier + synchronize bracket the timed region, MAX over ranks (dist.max_over_ranks).  tests/test_dist_cpu.py drives
+exactly those functions with 2 gloo ranks.
+
+Besides the headline the line carries: per-stage times of one batch on all CUs (`stages_ms`), the other single-GPU BASELINE
+configs (`c2_flow_only`, `c3_hift_only` with HBM- and MFMA-roofline fractions, exact-f32 beside bf16x3 products), three
+roofline blocks (`roofline` = the by-time dominant kernel of the pipeline, the flow's flash attention; `roofline_flow` = the
+flow stage on SURVEY §8d's 4.937 TF per utterance; `roofline_decode` = the decode step at step level, 727.6 MB per step, and
+its largest weight stream), and `cpu_baseline` (oracle, median of 3 warmed samples per component).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -34,11 +44,11 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def make_inputs(lc, fc, seed):
+def make_inputs(lc, fc, seed, n_utts=UTT_PER_GPU):
+    """The global utterance list (texts + forced token lists) and the one shared speaker prompt, identical on every rank."""
     g = torch.Generator().manual_seed(seed)
-    B = UTT_PER_GPU
-    texts = [torch.randint(0, lc.vocab_size, (1, L_TEXT), generator=g, dtype=torch.int32) for _ in range(B)]
-    forced = [torch.randint(0, lc.speech_token_size, (N_GEN,), generator=g).tolist() for _ in range(B)]
+    texts = [torch.randint(0, lc.vocab_size, (1, L_TEXT), generator=g, dtype=torch.int32) for _ in range(n_utts)]
+    forced = [torch.randint(0, lc.speech_token_size, (N_GEN,), generator=g).tolist() for _ in range(n_utts)]
     # shared prompt conditioning (one speaker prompt for the whole batch: what the broadcast carries)
     ptext = torch.randint(0, lc.vocab_size, (1, L_PTEXT), generator=g, dtype=torch.int32)
     pspeech = torch.randint(0, lc.speech_token_size, (1, N_PROMPT), generator=g, dtype=torch.int32)
@@ -47,46 +57,88 @@ def make_inputs(lc, fc, seed):
     return texts, forced, ptext, pspeech, pfeat, emb
 
 
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(lsd, fsd, hsd, lc, fc, hc):
-    """The oracle (CPU port of the reference arithmetic) timed on this host's cores on a bounded sample of the SAME
-    workload, extrapolated linearly in the repeated units (decode steps, Euler steps, mel frames)."""
+    """The oracle (CPU port of the reference arithmetic) timed on this host's cores on a bounded sample of the SAME workload:
+    every component is run once to warm (thread pool, allocator, page faults) and then three times, the MEDIAN is kept, and the
+    per-utterance time is extrapolated linearly in the repeated units (decode steps, Euler steps, mel frames)."""
     from oracle import flow as of
     from oracle import hift as oh
     from oracle import llm as ol
-    # the GPU box gives one GPU a 16-core CPU share; torch's default (all 128+ hardware threads) is far slower on these
-    # small ops than 16 threads, so the baseline is timed at its best setting
+    # the GPU box gives one GPU a 16-core CPU share; torch's default (all hardware threads) is far slower on these small ops
     cores = min(16, torch.get_num_threads())
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(1)
+
+    def med(fn, n=3):
+        fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts)
+
     with torch.inference_mode():
-        # LLM: prefill L=282 + 6 decode steps
-        x = torch.randn(1, 1 + L_PTEXT + L_TEXT + 1 + N_PROMPT, lc.hidden_size, generator=g) * 0.02
-        cache = ol.KVCache(lc.num_layers)
-        t0 = time.perf_counter(); y = ol.qwen2_forward(lsd, lc, x, cache); ol.logits_to_logp(lsd, y[:, -1]); t_pre = time.perf_counter() - t0
+        L = 1 + L_PTEXT + L_TEXT + 1 + N_PROMPT
+        x = torch.randn(1, L, lc.hidden_size, generator=g) * 0.02
         x1 = torch.randn(1, 1, lc.hidden_size, generator=g) * 0.02
-        ol.qwen2_forward(lsd, lc, x1, cache)
-        t0 = time.perf_counter()
-        for _ in range(6):
-            y = ol.qwen2_forward(lsd, lc, x1, cache); ol.logits_to_logp(lsd, y[:, -1])
-        t_step = (time.perf_counter() - t0) / 6
-        # flow: encoder N=500 once + ONE estimator call at T=1000 (CFG batch 2)
+
+        def prefill():
+            cache = ol.KVCache(lc.num_layers)
+            y = ol.qwen2_forward(lsd, lc, x, cache)
+            ol.logits_to_logp(lsd, y[:, -1])
+            return cache
+        t_pre = med(prefill)
+        cache = prefill()
+
+        def step4():   # 4 decode steps at context ~ 282..294 (the cache grows by 4 per call: 16 steps in all)
+            for _ in range(4):
+                y = ol.qwen2_forward(lsd, lc, x1, cache)
+                ol.logits_to_logp(lsd, y[:, -1])
+        t_step = med(step4) / 4
         N = N_PROMPT + N_GEN
         xs = torch.randn(1, N, fc.input_size, generator=g)
-        t0 = time.perf_counter(); of.encoder_forward(fsd, fc, xs, torch.tensor([N]), 0); t_enc = time.perf_counter() - t0
+        t_enc = med(lambda: of.encoder_forward(fsd, fc, xs, torch.tensor([N]), 0))
         T = 2 * N
         a = lambda *s: torch.randn(*s, generator=g)
-        t0 = time.perf_counter()
-        of.estimator_forward(fsd, fc, a(2, 80, T), torch.ones(2, 1, T), a(2, 80, T), torch.tensor([0.5, 0.5]), a(2, 80), a(2, 80, T))
-        t_est = time.perf_counter() - t0
-        # HiFT: 100 of the 500 frames
+        ex = (a(2, 80, T), torch.ones(2, 1, T), a(2, 80, T), torch.tensor([0.5, 0.5]), a(2, 80), a(2, 80, T))
+        t_est = med(lambda: of.estimator_forward(fsd, fc, *ex))
         mel = torch.clamp(a(1, 80, 100) * 2 - 6, -11.5, 2.0)
         ph, nz = oh.draw_source_randoms(hc, 1, 100 * hc.total_upsample, seed=2)
-        t0 = time.perf_counter(); oh.inference(hsd, hc, mel, None, ph, nz); t_hift = (time.perf_counter() - t0) * 5
-    per_utt = t_pre + (N_GEN - 1) * t_step + t_enc + fc.n_timesteps * t_est + t_hift
+        t_hift = med(lambda: oh.inference(hsd, hc, mel, None, ph, nz)) * 5
+    t_dec = (N_GEN - 1) * t_step
+    per_utt = t_pre + t_dec + t_enc + fc.n_timesteps * t_est + t_hift
     return {"value": round(AUDIO_S_PER_UTT / per_utt, 4), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
-            "sample": (f"oracle fp32, 1 utterance of the same workload: prefill L=282 ({t_pre:.2f}s) + 6 decode steps "
-                       f"({t_step*1e3:.1f} ms/step, x249) + flow encoder N=500 ({t_enc:.2f}s) + 1 estimator call T=1000 "
-                       f"({t_est:.2f}s, x10) + HiFT 100/500 frames (x5 = {t_hift:.2f}s); per-utterance {per_utt:.1f}s")}
+            "cpu_model": cpu_model_string(),
+            "stages_s": {"llm_prefill": round(t_pre, 3), "llm_decode": round(t_dec, 3), "flow_encoder": round(t_enc, 3),
+                         "flow_solver": round(fc.n_timesteps * t_est, 3), "hift": round(t_hift, 3), "per_utterance": round(per_utt, 2)},
+            "sample": (f"oracle fp32, 1 utterance of the same workload, every component warmed once then median of 3: prefill L=282 "
+                       f"({t_pre:.2f}s) + 4 decode steps ({t_step*1e3:.1f} ms/step, x249) + flow encoder N=500 ({t_enc:.2f}s) + 1 estimator "
+                       f"call T=1000 ({t_est:.2f}s, x10) + HiFT 100/500 frames (x5 = {t_hift:.2f}s)")}
+
+
+def ev_time(fn, n, warm=2):
+    """Seconds per call: n calls between HIP events on torch's current stream, after `warm` untimed calls."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / n
 
 
 def main():
@@ -95,6 +147,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the stage / C2 / C3 measurements (tuning runs)")
     ap.add_argument("--flow-dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--llm-cu-slots", type=int, default=8,
                     help="CU slots per XCD (of 32) owned by the decode loops while they overlap flow+HiFT; 0 = no partition")
@@ -123,6 +176,8 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    from cosyvoice_amd import dist as cd
+    from cosyvoice_amd import ops
     from cosyvoice_amd.config import FlowConfig, HiftConfig, LlmConfig
     from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
     from cosyvoice_amd.hift import HiFTGenerator
@@ -145,26 +200,26 @@ def main():
     flow.decoder.use_graph = True
     log(f"[rank {rank}] models on device in {time.time()-t0:.1f}s")
 
-    texts, forced, ptext, pspeech, pfeat, emb = make_inputs(lc, fc, seed=100 + rank)
+    # ---- the global utterance list (identical on every rank), sharded: rank r takes utterances {i : i mod world = r}
+    n_global = UTT_PER_GPU * world
+    texts, forced, ptext, pspeech, pfeat, emb = make_inputs(lc, fc, seed=100, n_utts=n_global)
+    mine = cd.shard_utterances(n_global, world, rank)
     dev = torch.device("cuda", local_rank)
-    B = UTT_PER_GPU
-    # conditioning buffer broadcast from rank 0: [prompt mel | speaker embedding | prompt speech tokens | prompt text ids]
-    n_feat, n_emb = pfeat.numel(), emb.numel()
-    cond_buf = torch.cat([pfeat.reshape(-1), emb.reshape(-1), pspeech.reshape(-1).float(), ptext.reshape(-1).float()]).to(dev)
-    texts_d = [t.to(dev) for t in texts]
+    B = len(mine)
+    texts_d = [texts[i].to(dev) for i in mine]
+    forced_m = [forced[i] for i in mine]
+    # conditioning payload [prompt mel | speaker embedding | prompt speech tokens | prompt text ids], one flat fp32 buffer
+    payload, layout = cd.pack_conditioning(pfeat, emb, pspeech, ptext)
+    cond_buf = payload.to(dev) if rank == 0 else torch.zeros_like(payload).to(dev)   # only rank 0 holds it before the broadcast
 
     def bcast():
-        if dist is not None:
-            dist.broadcast(cond_buf, src=0)
+        cd.broadcast_conditioning(cond_buf, dist, src=0)
 
     def make_batch():
-        pf = cond_buf[:n_feat].view(1, 2 * N_PROMPT, 80)
-        em = cond_buf[n_feat:n_feat + n_emb].view(1, -1)
-        ps = cond_buf[n_feat + n_emb:n_feat + n_emb + N_PROMPT].to(torch.int32).view(1, -1)
-        pt = cond_buf[n_feat + n_emb + N_PROMPT:].to(torch.int32).view(1, -1)
+        pf, em, ps, pt = cd.unpack_conditioning(cond_buf, layout)
         return dict(texts=texts_d, prompt_texts=[pt] * B, llm_prompt_speech_tokens=[ps] * B,
                     flow_prompt_speech_tokens=ps.expand(B, -1), prompt_speech_feats=pf.expand(B, -1, -1),
-                    flow_embeddings=em.expand(B, -1), forced=forced, on_start=bcast)
+                    flow_embeddings=em.expand(B, -1), forced=forced_m, on_start=bcast)
 
     def run_steps(n):
         """n pipeline passes ("steps", one batch of 8 utterances each): the decode loops of later passes (two at a time, on
@@ -180,6 +235,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    bcast()   # the payload is in place on every rank before the first batch is assembled
     if args.warmup > 0:
         w = run_steps(args.warmup)
         log(f"[rank {rank}] warmup: wav {tuple(w.shape)} absmax {w.abs().max().item():.3f}")
@@ -187,21 +243,25 @@ def main():
     t0 = time.perf_counter()
     run_steps(args.steps)
     fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = cd.max_over_ranks(time.perf_counter() - t0, dev, dist)
 
-    # ---- batch-1 latency of the same pipeline (BASELINE metric: "batch 1 and 8"; north_star target RTF < 0.05), rank 0 only
-    b1 = None
+    # what the collective layer saw: world size / backend of the process group and a SUM over ranks of the utterance counts
+    dist_info = {"world_size": 1, "backend": None, "utterances_per_rank": [B], "utterances_total_allreduce": B}
+    if dist is not None:
+        cnt = torch.tensor([B], device=dev if args.backend == "nccl" else "cpu", dtype=torch.int64)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                     "utterances_per_rank": [len(cd.shard_utterances(n_global, world, r)) for r in range(world)],
+                     "utterances_total_allreduce": int(cnt.item())}
+
+    out = None
     if rank == 0:
-        one = dict(texts=texts_d[:1], prompt_texts=[make_batch()["prompt_texts"][0]], llm_prompt_speech_tokens=[make_batch()["llm_prompt_speech_tokens"][0]],
-                   flow_prompt_speech_tokens=make_batch()["flow_prompt_speech_tokens"][:1], prompt_speech_feats=make_batch()["prompt_speech_feats"][:1],
-                   flow_embeddings=make_batch()["flow_embeddings"][:1], forced=forced[:1])
+        one = make_batch()
+        # ---- batch-1 latency of the same pipeline (BASELINE metric: "batch 1 and 8"; north_star target RTF < 0.05)
         def run1():
-            return model.tts_batch(one["texts"], one["prompt_texts"], one["llm_prompt_speech_tokens"], one["flow_prompt_speech_tokens"],
-                                   one["prompt_speech_feats"], one["flow_embeddings"], forced=one["forced"], to_host=True)
+            return model.tts_batch(one["texts"][:1], one["prompt_texts"][:1], one["llm_prompt_speech_tokens"][:1],
+                                   one["flow_prompt_speech_tokens"][:1], one["prompt_speech_feats"][:1], one["flow_embeddings"][:1],
+                                   forced=forced_m[:1], to_host=True)
         for _ in range(2):
             run1()
         torch.cuda.synchronize()
@@ -213,11 +273,12 @@ def main():
         lat = (time.perf_counter() - t1) / n1
         b1 = {"latency_ms": round(lat * 1e3, 2), "rtf": round(lat / AUDIO_S_PER_UTT, 5), "audio_s_per_s": round(AUDIO_S_PER_UTT / lat, 2)}
 
-    # ---- roofline of the dominant kernel, measured live with events on the launch stream
-    roof = measure_roofline(llm, lc, rows=min(llm.max_batch, UTT_PER_GPU * max(1, args.llm_merge)))
-
-    out = None
-    if rank == 0:
+        extras = {}
+        if not args.no_extras:
+            extras = measure_extras(model, llm, flow, hift, lc, fc, hc, one, forced_m, fdt, args)
+        replay = ("each decode step is ONE captured hipGraph, replayed node by node (hipLaunchKernel per captured kernel) on CU-masked "
+                  "streams because hipGraph replays ignore a stream's CU mask" if args.llm_cu_slots else
+                  "each decode step is ONE captured hipGraph replayed with hipGraphLaunch")
         audio_s = AUDIO_S_PER_UTT * B * world * args.steps
         out = {
             "metric": "audio-seconds/sec (RTF^-1) end-to-end, 10s prompt, batch 8",
@@ -227,33 +288,134 @@ def main():
             "dtype": f"llm bf16 / flow {args.flow_dtype} MFMA operands, fp32 accumulate; hift fp32 tensors, bf16x3 split-product MFMA",
             "data": "synthetic (key-seeded random weights of the reference architecture, teacher-forced 250 tokens)",
             "config": {"workload": "C4 full LLM->flow->HiFT pipeline, 8 utterances x 10 s per GPU, 10 s prompt "
-                                   "(prefill 282, N_g 250, flow T 1000 x 10 CFG Euler steps, HiFT 500 frames)",
+                                   "(prefill 282, N_g 250, flow T 1000 x 10 CFG Euler steps, HiFT 500 frames); token loop: " + replay,
                        "utterances_per_gpu": B, "rtf": round(elapsed / audio_s, 6), "parallelism": f"utterance-parallel x{world}",
-                       "llm_cu_slots_per_xcd": args.llm_cu_slots, "llm_decode_loops": args.llm_loops, "batches_per_decode_loop": args.llm_merge, "batch1": b1},
-            "roofline": roof,
+                       "llm_cu_slots_per_xcd": args.llm_cu_slots, "llm_decode_loops": args.llm_loops, "batches_per_decode_loop": args.llm_merge,
+                       "flow_fused_tblock": bool(flow.decoder.estimator.fused), "batch1": b1, "dist": dist_info},
         }
+        out.update(extras)
+        if "roofline" not in out:
+            out["roofline"] = measure_decode_roofline(llm, lc, rows=min(llm.max_batch, UTT_PER_GPU * max(1, args.llm_merge)))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lsd, fsd, hsd, lc, fc, hc)
         print(json.dumps(out), flush=True)
+    fence()
+    model.close()
+    ops.close()
     if dist is not None:
-        dist.barrier()
         dist.destroy_process_group()
 
 
-def measure_roofline(llm, lc, rows=UTT_PER_GPU):
-    """Roofline kernel = the decode step's gate/up skinny GEMM (exactly one shape in this workload, so the rocprof
+def measure_extras(model, llm, flow, hift, lc, fc, hc, one, forced_m, fdt, args):
+    """Stage times of one batch (all CUs, stages run back to back, not overlapped), the flow / decode rooflines and BASELINE
+    configs C2 / C3.  Rank 0, outside the timed region."""
+    from cosyvoice_amd import ops
+    from cosyvoice_amd.config import FlowConfig, HiftConfig
+    from cosyvoice_amd.hift import HiFTGenerator
+    from cosyvoice_amd.weights import hift_state_dict
+    dev = "cuda"
+    B = len(one["texts"])
+    res = {}
+    # ---------------- LLM: prefill (+ first token) vs the 249 decode steps, batch 8, graph replays on all CUs
+    gb = lambda steps: llm.generate_batch(one["texts"], one["prompt_texts"], one["llm_prompt_speech_tokens"], forced=forced_m,
+                                          steps_per_poll=64, max_steps=steps)
+    t_pre = ev_time(lambda: gb(1), 3, warm=1)
+    t_llm = ev_time(lambda: gb(None), 2, warm=1)
+    toks = gb(None)
+    # ---------------- flow: encoder vs solver (+ glue), batch 8, T = 1000
+    tok = torch.tensor(toks, dtype=torch.int32, device=dev)
+    fargs = (tok, one["flow_prompt_speech_tokens"], one["prompt_speech_feats"], one["flow_embeddings"])
+    t_flow = ev_time(lambda: flow.inference_batch(*fargs), 4, warm=2)
+    N = N_PROMPT + N_GEN
+    ews = flow.encoder._workspace(B, N)
+    t_enc = ev_time(lambda: flow.encoder.forward_tokens(ews["tok"], B, N), 4, warm=1)
+    mel = flow.inference_batch(*fargs).clone().contiguous()
+    zero = torch.zeros(1, 1, 0)
+    t_hift = ev_time(lambda: hift.inference(speech_feat=mel, cache_source=zero), 6, warm=2)
+    hift_x = HiFTGenerator(hc, dtype=torch.float32, f32_products="exact").load_state_dict(hift_state_dict(hc))
+    t_hift_x = ev_time(lambda: hift_x.inference(speech_feat=mel, cache_source=zero), 4, warm=2)
+    res["stages_ms"] = {"note": "one batch of 8 utterances, stages run back to back on all 256 CUs (in the pipeline they overlap on disjoint CU sets)",
+                        "llm_prefill": round(t_pre * 1e3, 2), "llm_decode_249_steps": round((t_llm - t_pre) * 1e3, 2),
+                        "flow_encoder": round(t_enc * 1e3, 2), "flow_solver_10_steps": round((t_flow - t_enc) * 1e3, 2),
+                        "hift_bf16x3": round(t_hift * 1e3, 2), "hift_exact_f32": round(t_hift_x * 1e3, 2)}
+    del hift_x
+    # ---------------- rooflines
+    tf_flow = 4.937 * B   # SURVEY.md §8d: estimator flops per utterance at T = 1000, 10 steps
+    res["roofline_flow"] = {"bound": "mfma", "what": "flow stage (encoder + 10 CFG Euler steps), batch 8, T = 1000, all CUs",
+                            "achieved": round(tf_flow / t_flow, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf_flow / t_flow / 2500.0, 4),
+                            "flops": tf_flow * 1e12, "ms": round(t_flow * 1e3, 2), "traffic": None}
+    res["roofline"] = measure_attention_roofline(flow, B)
+    rows = min(llm.max_batch, UTT_PER_GPU * max(1, args.llm_merge))
+    dec = measure_decode_roofline(llm, lc, rows=rows)
+    step_s = (t_llm - t_pre) / (N_GEN - 1)
+    # SURVEY.md §8d: 2 (P_layers + P_head) weight bytes + KV: B ctx 12 288 + B 12 288, ctx ~ 282 + 125 on average
+    step_bytes = 2 * (357_897_216 + 896 + 5_887_908) + B * (407 + 1) * 12288
+    dec["step_level"] = {"what": f"whole decode step (124 launches, one hipGraph replay), {B} sequences, all CUs", "bytes_per_step": step_bytes,
+                         "us_per_step": round(step_s * 1e6, 1), "achieved": round(step_bytes / step_s / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(step_bytes / step_s / 8e12, 4)}
+    res["roofline_decode"] = dec
+    # ---------------- C2: flow-matching decoder only, one utterance, 80 mel x 500 frames, 10 Euler steps
+    tok1 = tok[:1]
+    ptok0 = torch.zeros(1, 0, dtype=torch.int32, device=dev)
+    pfeat0 = torch.zeros(1, 0, 80, device=dev)
+    c2args = (tok1, ptok0, pfeat0, one["flow_embeddings"][:1])
+    t_c2 = ev_time(lambda: flow.inference_batch(*c2args), 5, warm=2)
+    res["c2_flow_only"] = {"workload": "C2: flow-matching decoder only, 1 utterance, 250 tokens -> 80 mel x 500 frames, encoder + 10 CFG Euler steps",
+                           "dtype": str(fdt).replace("torch.", ""), "ms": round(t_c2 * 1e3, 2), "tflops": round(1.895 / t_c2, 1),
+                           "frac_of_2.5PF": round(1.895 / t_c2 / 2500.0, 4),
+                           "note": "batch 1: ~6 000 dependent launches in one hipGraph, launch-latency bound; bf16 operands miss the 1e-3 mel "
+                                   "target (DESIGN.md §2), so the bench default is fp16"}
+    # ---------------- C3: HiFT only, v1 22.05 kHz generator, 10 s of mel (861 frames -> 220 416 samples)
+    hc1 = HiftConfig.v1()
+    hsd1 = hift_state_dict(hc1)
+    mel1 = torch.clamp(torch.randn(1, 80, 861, device=dev) * 2 - 6, -11.5, 2.0)
+    c3 = {"workload": "C3: HiFT only, v1 22.05 kHz generator, 10 s of mel (861 frames -> 220 416 samples), fp32 tensors",
+          "flops": 518.37e9, "compulsory_bytes_fp32": (457.6e6 + 20.46e6) * 4}
+    for mode in ("bf16x3", "exact"):
+        h1 = HiFTGenerator(hc1, dtype=torch.float32, f32_products=mode).load_state_dict(hsd1)
+        t = ev_time(lambda: h1.inference(speech_feat=mel1, cache_source=zero), 6, warm=2)
+        mf = 518.37e9 * (3 if mode == "bf16x3" else 1) / t / 1e12   # MFMA work actually issued: three bf16 products per fp32 product
+        c3[mode] = {"ms": round(t * 1e3, 3), "rtf": round(t / 10.0, 6),
+                    "hbm_frac": round(c3["compulsory_bytes_fp32"] / t / 8e12, 4),
+                    "mfma_tflops_issued": round(mf, 1), "mfma_frac": round(mf / (2500.0 if mode == "bf16x3" else 157.3), 4)}
+        del h1
+    res["c3_hift_only"] = c3
+    return res
+
+
+def measure_attention_roofline(flow, B):
+    """The by-time dominant kernel of the pipeline: the estimator's flash attention (`attn_kernel`, 560 launches per batch =
+    ~44 % of the flow stage).  One launch = all 8 heads x 2 B CFG rows at T = 1000: 4 R H T^2 64 flop; 20 launches captured
+    once and replayed between HIP events on the stream they run on."""
+    from cosyvoice_amd import ops
+    est = flow.decoder.estimator
+    cfg = flow.cfg
+    R, T = 2 * B, 2 * (N_PROMPT + N_GEN)
+    ws = est._workspace(R, T)
+    H, inner, Tp = cfg.est_heads, cfg.est_inner, ws["Tp"]
+
+    def launch():
+        ops.attention(ws["qk"], ws["qk"][:, :, inner:], ws["vt"], ws["ao"], B=R, H=H, Hkv=H, Tq=T, Tk=T, scale=cfg.est_head_dim ** -0.5,
+                      q_bs=T * 2 * inner, ldq=2 * inner, k_bs=T * 2 * inner, ldk=2 * inner, vt_ld=Tp, o_bs=T * inner, ldo=inner)
+    n = 20
+    g = ops.Graph().capture(lambda: [launch() for _ in range(n)])
+    dur = ev_time(g.launch, 5, warm=2) / n
+    g.destroy()
+    flops = 4.0 * R * H * T * T * 64
+    return {"bound": "mfma", "kernel": f"attn_kernel<f16> (flow estimator flash attention, {R} rows x {H} heads x T={T}, head_dim 64)",
+            "achieved": round(flops / dur / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flops / dur / 2.5e15, 4),
+            "traffic": None, "flops_per_launch": flops, "avg_launch_us": round(dur * 1e6, 2),
+            "note": "algorithmic flops per launch = 4 R H T^2 d (QK^T and PV), SURVEY.md §8d's 2048 T flop per row per block"}
+
+
+def measure_decode_roofline(llm, lc, rows=UTT_PER_GPU):
+    """The decode step's largest weight stream: the gate/up skinny GEMM (exactly one shape in this workload, so the rocprof
     per-kernel average and this live measurement describe the same launches): it streams the layer's 2*4864*896 bf16
-    gate/up weights once per launch for all ``rows`` sequences of a token loop (8 utterances x the batches one decode loop
-    carries) — the largest weight stream of the HBM-bound decode stage (47 % of kernel time).  Algorithmic bytes per launch:
-    DESIGN.md §6."""
+    gate/up weights once per launch for all ``rows`` sequences of a token loop.  Algorithmic bytes per launch: DESIGN.md §6."""
     from cosyvoice_amd import ops
     st, lay = llm.st, llm.layers
     H, I = lc.hidden_size, lc.intermediate_size
     B = rows
-    n_iter = 50
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    # cycle through all 24 layers' weights (417 MB > 256 MB Infinity Cache) so every launch streams from HBM
     split = llm.split_norm
     npart = st["ssp"].shape[0]
 
@@ -265,16 +427,10 @@ def measure_roofline(llm, lc, rows=UTT_PER_GPU):
             ops.skinny_gemm(st["xn"], l["p_gu"], B, 2 * I, H, mode=2, out_act=st["h"], ldoa=I,
                             norm=dict(x=st["x2"], gamma=l["g_post"], eps=lc.rms_eps))
 
-    # the 24 launches are captured once and replayed: issued one by one from Python the host (~10 us per call) would be
-    # the thing timed, not the 7 us kernel.  HIP events bracket the replays on the stream they run on.
+    # the 24 layers' launches (417 MB of weights > Infinity Cache) are captured once and replayed between HIP events
     g = ops.Graph().capture(lambda: [launch(l) for l in lay])
-    g.launch()
-    ev0.record()
-    for _ in range(n_iter):
-        g.launch()
-    ev1.record()
-    torch.cuda.synchronize()
-    dur = ev0.elapsed_time(ev1) * 1e-3 / (n_iter * len(lay))
+    dur = ev_time(g.launch, 50, warm=2) / len(lay)
+    g.destroy()
     if split:
         alg = 2 * I * H * 2 + B * H * 2 + npart * 16 * 4 + B * I * 2   # packed bf16 weights + bf16 rows + partial sums + bf16 SwiGLU out
     else:
@@ -287,11 +443,7 @@ def measure_roofline(llm, lc, rows=UTT_PER_GPU):
             traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
-    note = (f"one launch streams the layer's gate/up weights for {B} sequences ({max(1, B // UTT_PER_GPU)} batch(es) per token loop); the "
-            "post-attention RMSNorm is split over the o_proj launch (16-bit rows + per-workgroup partial sums of squares) and this "
-            "kernel's epilogue (1/rms; gamma folded into the packed weights), so no prologue sits in front of the MFMAs "
-            "(fused-prologue form: 7.4 us at 8 rows, 9.2-9.5 us at 16; tools/roofline_time.py)") if split else None
-    return {"note": note, "bound": "hbm", "kernel": (f"skinny_kernel<bf16,TPW=2,no prologue,U=7,RS> (decode gate/up, split RMSNorm: 1/rms in the epilogue, + SwiGLU), {B} rows" if split else
+    return {"bound": "hbm", "kernel": (f"skinny_kernel<bf16,TPW=2,no prologue,U=7,RS> (decode gate/up, split RMSNorm: 1/rms in the epilogue, + SwiGLU), {B} rows" if split else
                        f"skinny_kernel<bf16,TPW=2,norm,TPR={32 if B <= 8 else 16},U=7> (decode gate/up + RMSNorm prologue + SwiGLU), {B} rows"),
             "achieved": round(alg / dur / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg / dur / 8e12, 4),
             "traffic": traffic, "bytes_per_launch": alg, "avg_launch_us": round(dur * 1e6, 3)}

@@ -125,6 +125,7 @@ class SampleParams(C.Structure):
         ("out_tokens", _vp), ("out_ld", _i32),
         ("emb_table", _vp), ("emb_dim", _i32),
         ("x", _vp), ("ldx", _i32),
+        ("nonce", _vp),
     ]
 
 

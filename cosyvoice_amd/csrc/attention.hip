@@ -5,8 +5,8 @@
 //   * a lane holds 16 keys of ONE query per 64-key tile: the softmax row reduction is in-lane + 2 cross-lane steps;
 //   * the S^T accumulator registers are, after exp and 16-bit packing, directly the B operand of O^T += V^T . P^T
 //     (k-slot (g,j<4) = key 16*kt0+4g+j, (g,j>=4) = key 16*kt1+4g+j-4): no LDS round trip for P;
-//   * V arrives pre-transposed (V^T [d][key], written by the QKV GEMM epilogue), so its A fragment is two 8-byte
-//     LDS reads per lane from a [64 d][128 B] image with XOR-swizzled 16-byte chunk slots.
+//   * V arrives pre-transposed (V^T [d][key], written by the QKV producer), so its A fragment is ONE 16-byte
+//     LDS read per lane from a [64 d][128 B] image with XOR-swizzled 16-byte chunk slots.
 // K / V^T tiles (64 keys) are staged through LDS, double-buffered with register prefetch (one barrier per tile).
 #include "cv_device.h"
 
@@ -206,6 +206,12 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const cv_attn_params p) {
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = __builtin_amdgcn_exp2f(fmaf(sacc[kt][qt][r], sc, -mnew));
+      }
+      // a query with no visible key so far (negative causal_off, klen 0): every masked score equals the running "max", exp2(0) = 1
+      // would count the masked keys.  Zero the probabilities while the running max is still the mask value: the row ends as zeros.
+      if (mnew <= 0.5f * NEG_BIG * fminf(sc, 1.0f)) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) sacc[kt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       }
       // v_exp_f32 directly (exp2f's denormal handling costs four more VALU per element; a flushed 2^-127 is 0 here anyway)
       const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);

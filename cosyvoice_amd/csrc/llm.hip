@@ -861,6 +861,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const cv_sample_params p) {
   const int min_len_b = p.min_len[b];
   const int n_em = p.n_emitted[b];
   const int max_len_b = p.max_len[b];
+  const uint64_t key = p.seed ^ (p.nonce ? p.nonce[0] : 0ull);
   // the last win_size emitted ids, one per lane (repetition check, utils/common.py:111-113)
   const int widx = n_em - p.win_size + lane;
   const int recent = p.out_tokens[(int64_t)b * p.out_ld + min(max(widx, 0), p.out_ld - 1)];
@@ -1012,7 +1013,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const cv_sample_params p) {
         u2 = p.uniforms[((int64_t)b * (p.max_trials + 1) + trial) * 2 + 1];
       } else {
         const uint4 r = philox4x32_10(make_uint4((uint32_t)step, (uint32_t)b, (uint32_t)trial, 0u),
-                                      make_uint2((uint32_t)p.seed, (uint32_t)(p.seed >> 32)));
+                                      make_uint2((uint32_t)key, (uint32_t)(key >> 32)));
         u1 = u01(r.x);
         u2 = u01(r.y);
       }

@@ -132,7 +132,7 @@ class Qwen2LM:
                        n_emitted=z(16, dtype=torch.int32), finished=z(16, dtype=torch.int32), min_len=z(16, dtype=torch.int32),
                        max_len=z(16, dtype=torch.int32), out_tokens=z(16, self.max_out, dtype=torch.int32),
                        forced=torch.full((16, self.max_out), -1, device=dev, dtype=torch.int32),
-                       uniforms=z(16, 101, 2))
+                       uniforms=z(16, 101, 2), nonce=z(2, dtype=torch.int64))
         self.kcache = [z(MB, cfg.num_kv_heads, self.ctx_max, 64, dtype=dt) for _ in range(cfg.num_layers)]
         self.vtcache = [z(MB, cfg.num_kv_heads, 64, self.ctx_max, dtype=dt) for _ in range(cfg.num_layers)]
 
@@ -156,7 +156,15 @@ class Qwen2LM:
         p.out_tokens, p.out_ld = st["out_tokens"].data_ptr(), self.max_out
         p.emb_table, p.emb_dim = self.speech_embedding.data_ptr(), H
         p.x, p.ldx = st["x"].data_ptr(), H
+        p.nonce = st["nonce"].data_ptr()
         ops.sample_ras(p)
+
+    def _new_request_nonce(self):
+        """Fresh Philox key material for one request, drawn from torch's global (CPU) generator: consecutive requests and
+        concurrent decode contexts get different streams, ``torch.manual_seed`` reproduces them, and the captured step graph
+        (which only holds the buffer's address) stays valid.  The reference samples from torch's global RNG as well
+        (utils/common.py:139 torch.multinomial)."""
+        self.st["nonce"].copy_(torch.randint(0, 2 ** 62, (2,), dtype=torch.int64))
 
     def _decode_step(self, B, use_forced=False, use_uniforms=False):
         cfg, st = self.cfg, self.st
@@ -348,6 +356,8 @@ class Qwen2LM:
         use_uniforms = uniforms is not None
         if use_uniforms:
             st["uniforms"].copy_(uniforms.to(torch.float32))
+        else:
+            self._new_request_nonce()
         if prefill_stream is not None:
             cur = torch.cuda.current_stream()
             prefill_stream.wait_stream(cur)            # the state resets above
@@ -395,6 +405,7 @@ class Qwen2LM:
             raise ValueError("ctx_max too small for this request")
         st["min_len"].fill_(min_len)
         st["max_len"].fill_(max_len)
+        self._new_request_nonce()
         self._assemble(ws, [text], [prompt_text], [prompt_speech_token], B, Lp, None if lm_input is None else [lm_input])
         self._prefill(B, Lp, False, False)
         sent, steps = 0, 1

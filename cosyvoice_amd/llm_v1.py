@@ -209,7 +209,7 @@ class TransformerLM:
         self.st = dict(x=z(16, c.llm_dim), h=z(16, c.llm_dim, dtype=dt), logits=z(16, self.Vpad), pos=z(16, dtype=torch.int32),
                        step=z(16, dtype=torch.int32), n_emitted=z(16, dtype=torch.int32), finished=z(16, dtype=torch.int32),
                        min_len=z(16, dtype=torch.int32), max_len=z(16, dtype=torch.int32),
-                       out_tokens=z(16, self.max_len, dtype=torch.int32), uniforms=z(16, 101, 2))
+                       out_tokens=z(16, self.max_len, dtype=torch.int32), uniforms=z(16, 101, 2), nonce=z(2, dtype=torch.int64))
         self.stack.build_decoder(self.max_len, self.seq, self.st["h"])
         self.incremental = True      # False: recompute the full causal pass every step (the cross-check of the cached path)
         self._cached = 0             # rows of the current request whose keys / values are in the caches
@@ -269,7 +269,11 @@ class TransformerLM:
         p.eos, p.top_k, p.top_p, p.win_size, p.tau_r = c.speech_token_size, c.top_k, c.top_p, c.win_size, c.tau_r
         p.fallback_mode, p.top_p2, p.top_k2 = 1, c.top_p + 0.15, c.top_k * c.expand_scale
         p.seed = self.seed
+        p.nonce = st["nonce"].data_ptr()
         p.uniforms = st["uniforms"].data_ptr() if use_uniforms else None
+        # the fork's TransformerLM.sampling_ids draws ONCE (its retry loop is commented out, llm.py:157-169): an EOS sampled at
+        # 0 < i < min_len simply ends decoding; only step 0 is protected, by the -inf mask on the log-probs (:227-229).
+        # min_len is therefore 0 for the sampler (no redraw), unlike the Qwen2LM classes (llm.py:806-821)
         p.max_trials = 100
         p.min_len, p.max_len = st["min_len"].data_ptr(), st["max_len"].data_ptr()
         p.forced, p.forced_ld = forced_ptr, forced_ld
@@ -295,10 +299,12 @@ class TransformerLM:
         for k in ("step", "n_emitted", "finished", "pos"):
             st[k].zero_()
         st["finished"][1:].fill_(1)
-        st["min_len"].fill_(min_len)
+        st["min_len"].fill_(0)          # no EOS redraw in this LM (see _sample)
         st["max_len"].fill_(max_len)
         if uniforms is not None:
             st["uniforms"].copy_(uniforms.to(torch.float32))
+        else:
+            st["nonce"].copy_(torch.randint(0, 2 ** 62, (2,), dtype=torch.int64))
         fbuf = None
         if forced is not None:
             fbuf = torch.full((1, self.max_len), -2, device=dev, dtype=torch.int32)

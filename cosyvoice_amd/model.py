@@ -193,7 +193,7 @@ class CosyVoice2Model:
                                    flow_embeddings=flow_embeddings), toks)
         if isinstance(wav, list):   # sequences of different generated lengths
             return [w.cpu() for w in wav] if to_host else wav
-        return wav.cpu() if to_host else wav
+        return wav.cpu() if to_host else wav.clone()   # never hand out a view of HiFT's per-shape workspace
 
     def cu_partition(self, llm_cu_slots: int, n_llm: int = 1):
         """(llm_streams, flow_stream): CU-masked streams giving the decode loop(s) ``llm_cu_slots`` of the 32 CUs of every XCD
@@ -204,6 +204,7 @@ class CosyVoice2Model:
         from . import ops
         key = (llm_cu_slots, n_llm)
         if getattr(self, "_cu_partition_key", None) != key:
+            self._release_partition()   # the previous split's streams are destroyed, not leaked
             k = llm_cu_slots
             self._cu_partition = ([ops.masked_stream(lambda s, x: s < k) for _ in range(n_llm)],
                                   ops.masked_stream(lambda s, x: s >= k),
@@ -211,6 +212,30 @@ class CosyVoice2Model:
                                   [ops.masked_stream(lambda s, x: s >= k) for _ in range(n_llm)])  # prefills, on the flow CUs
             self._cu_partition_key = key
         return self._cu_partition
+
+    def _release_partition(self):
+        from . import ops
+        part = getattr(self, "_cu_partition", None)
+        if part is not None:
+            torch.cuda.synchronize()
+            flat = list(part[0]) + [part[1], part[2]] + list(part[3])
+            for st in flat:
+                ops.destroy_masked_stream(st)
+        self._cu_partition, self._cu_partition_key = None, None
+
+    def close(self):
+        """Release what this model holds inside the HIP runtime (captured graphs of every stage / decode context, CU-masked
+        streams) while the runtime is alive.  The model stays usable: graphs and streams are rebuilt on demand."""
+        torch.cuda.synchronize()
+        for ctx in getattr(self, "_llm_contexts", None) or [self.llm]:
+            for g in getattr(ctx, "_graphs", {}).values():
+                g.destroy()
+            getattr(ctx, "_graphs", {}).clear()
+        dec = getattr(self.flow, "decoder", None)
+        for g in getattr(dec, "_graphs", {}).values():
+            g.destroy()
+        getattr(dec, "_graphs", {}).clear()
+        self._release_partition()
 
     def llm_contexts(self, n: int):
         """``n`` decode contexts over the one set of LLM weights (Qwen2LM.new_context)."""
@@ -306,6 +331,9 @@ class CosyVoice2Model:
                 wav = self._flow_hift(b, toks)
                 if to_host:
                     return ([w.cpu() for w in wav] if isinstance(wav, list) else wav.cpu()), None
+                # the equal-length path returns a view of HiFT's per-shape workspace, which the next flow_job overwrites on this
+                # stream as soon as its tokens arrive: hand the consumer its own copy (made here, ordered before `done`)
+                wav = [w.clone() for w in wav] if isinstance(wav, list) else wav.clone()
                 done = torch.cuda.Event()
                 done.record(stream)
                 return wav, done

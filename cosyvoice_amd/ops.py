@@ -1,7 +1,9 @@
 """Thin tensor-level wrappers over the C ABI (device pointers out of torch tensors; torch is plumbing only)."""
+import atexit
 import ctypes as C
 import sys
 import threading
+import weakref
 
 import torch
 
@@ -307,10 +309,12 @@ def interp_linear_cl(x, y):
 
 
 class Graph:
-    """hipGraph of a launch sequence issued through the ABI on torch's current stream."""
+    """hipGraph of a launch sequence issued through the ABI on torch's current stream.  Every live graph is registered so that
+    ``ops.close()`` (also an atexit hook) can destroy it while the HIP runtime is still alive."""
 
     def __init__(self):
         self.handle = C.c_void_p(None)
+        _GRAPHS.add(self)
 
     def capture(self, fn):
         # capture needs a non-default stream; replays may go to any stream
@@ -342,16 +346,60 @@ class Graph:
     def num_launches(self):
         return L.lib().cv_graph_num_launches(self.handle)
 
+    def destroy(self):
+        """Release the hipGraph / hipGraphExec now (idempotent).  The owner must have drained the streams it was launched on."""
+        h, self.handle = self.handle, C.c_void_p(None)
+        if h:
+            L.lib().cv_graph_destroy(h)
+
     def __del__(self):
-        # not at interpreter shutdown: the HIP runtime (and a profiler attached to it) may already be finalising
+        # objects collected after close() / at interpreter shutdown hold no handle any more (close() ran from atexit while the
+        # runtime was alive); never call into HIP from a finalising interpreter
         try:
             if self.handle and not sys.is_finalizing():
-                L.lib().cv_graph_destroy(self.handle)
+                self.destroy()
         except Exception:
             pass
 
 
-_MASKED_STREAMS = set()  # raw handles of the CU-masked streams made here: Graph.launch issues direct launches on them
+_GRAPHS = weakref.WeakSet()
+_MASKED_STREAMS = {}  # raw handle -> ExternalStream of the CU-masked streams made here: Graph.launch issues direct launches on them
+
+
+def destroy_masked_stream(stream):
+    """hipStreamDestroy of a stream made by ``masked_stream`` (after draining it) and removal from the registry, so that a
+    recycled handle value is never mistaken for a masked stream."""
+    h = stream.cuda_stream
+    if _MASKED_STREAMS.pop(h, None) is not None:
+        stream.synchronize()
+        L.check(L.lib().cv_stream_destroy(C.c_void_p(h)), "cv_stream_destroy")
+
+
+def close():
+    """Drain the device and release everything this module created through the ABI that the HIP runtime owns: captured graphs
+    and CU-masked streams.  Registered with atexit (after torch's own hooks, so it runs before them): objects owned by the
+    runtime that outlive it were what made profiled runs abort inside __cxa_finalize (round-1 records)."""
+    if not _GRAPHS and not _MASKED_STREAMS:
+        return
+    try:
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except Exception:
+        pass
+    for g in list(_GRAPHS):
+        try:
+            g.destroy()
+        except Exception:
+            pass
+    for h, st in list(_MASKED_STREAMS.items()):
+        try:
+            L.lib().cv_stream_destroy(C.c_void_p(h))
+        except Exception:
+            pass
+    _MASKED_STREAMS.clear()
+
+
+atexit.register(close)
 
 
 def masked_stream(keep, n_xcd=8, slots=32, device=None):
@@ -369,8 +417,9 @@ def masked_stream(keep, n_xcd=8, slots=32, device=None):
     st = C.c_void_p()
     L.check(L.lib().cv_stream_create_cumask(words, len(words), C.byref(st)), "cv_stream_create_cumask")
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    _MASKED_STREAMS.add(st.value)
-    return torch.cuda.ExternalStream(st.value, device=dev)
+    ext = torch.cuda.ExternalStream(st.value, device=dev)
+    _MASKED_STREAMS[st.value] = ext
+    return ext
 
 
 # ----------------------------------------------------------------------------- LLM decode helpers

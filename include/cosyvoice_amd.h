@@ -330,6 +330,10 @@ typedef struct cv_sample_params {
   int32_t* out_tokens; int32_t out_ld;              /* [B][out_ld] */
   const float* emb_table; int32_t emb_dim;          /* speech_embedding.weight fp32 */
   float* x; int32_t ldx;      /* next-step input embedding [B][ldx] */
+  /* optional per-request nonce (device, one uint64): XORed into the Philox key, so a captured step graph (seed is baked into
+     its kernel arguments) still draws a fresh stream for every request — the reference draws from torch's global RNG
+     (utils/common.py:139).  The counter stays (step, row, trial). */
+  const uint64_t* nonce;
 } cv_sample_params;
 int cv_sample_ras(const cv_sample_params* p, void* stream);
 int cv_sizeof_gemm_params(void);

@@ -78,3 +78,35 @@ def test_attention_vs_torch(dt, B, H, Hkv, Tq, Tk, mode):
     assert torch.isfinite(o).all()
     err = (o - ref).abs().max().item()
     assert err < (3e-2 if dt == torch.bfloat16 else 4e-3), err
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_fully_masked_query_rows_are_zero(dt, with_bias):
+    """A negative causal_off leaves the first queries without any visible key: those rows must come out as zeros (every masked
+    score used to equal the running "max", so exp2(0) = 1 gave them mean(V) of the loaded tiles); the other rows are unaffected."""
+    from cosyvoice_amd import ops
+    torch.manual_seed(1)
+    dev, B, H, T, off = "cuda", 1, 4, 150, -5
+    q = torch.randn(B, T, H * 64, device=dev).to(dt)
+    k = torch.randn(B, T, H * 64, device=dev).to(dt)
+    v = torch.randn(B, T, H * 64, device=dev).to(dt)
+    Tp = (T + 63) // 64 * 64
+    vt = torch.zeros(B, H, 64, Tp, device=dev, dtype=dt)
+    vt[..., :T] = v.view(B, T, H, 64).permute(0, 2, 3, 1)
+    out = torch.full((B, T, H * 64), 7.0, device=dev, dtype=dt)
+    kw, rkw = {}, {}
+    if with_bias:
+        bias = torch.randn(B, H, T, T, device=dev)
+        kw.update(bias=bias, bias_bs=H * T * T, bias_hs=T * T, bias_ld=T)
+        rkw["bias"] = bias
+    scale = 0.125
+    ops.attention(q, k, vt, out, B=B, H=H, Hkv=H, Tq=T, Tk=T, scale=scale, q_bs=T * H * 64, ldq=H * 64, k_bs=T * H * 64,
+                  ldk=H * 64, vt_ld=Tp, o_bs=T * H * 64, ldo=H * 64, causal=True, causal_off=off, **kw)
+    torch.cuda.synchronize()
+    o = out.float()
+    assert o[:, :-off].abs().max().item() == 0.0
+    ref = _ref(q.float().view(B, T, H, 64).transpose(1, 2), k.float().view(B, T, H, 64).transpose(1, 2),
+               v.float().view(B, T, H, 64).transpose(1, 2), scale, causal=True, causal_off=off, **rkw).transpose(1, 2).reshape(B, T, H * 64)
+    err = (o[:, -off:] - ref[:, -off:]).abs().max().item()
+    assert err < (3e-2 if dt == torch.bfloat16 else 4e-3), err
