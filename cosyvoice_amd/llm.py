@@ -159,12 +159,15 @@ class Qwen2LM:
         p.nonce = st["nonce"].data_ptr()
         ops.sample_ras(p)
 
-    def _new_request_nonce(self):
+    def _new_request_nonce(self, nonce=None):
         """Fresh Philox key material for one request, drawn from torch's global (CPU) generator: consecutive requests and
         concurrent decode contexts get different streams, ``torch.manual_seed`` reproduces them, and the captured step graph
         (which only holds the buffer's address) stays valid.  The reference samples from torch's global RNG as well
         (utils/common.py:139 torch.multinomial)."""
-        self.st["nonce"].copy_(torch.randint(0, 2 ** 62, (2,), dtype=torch.int64))
+        if nonce is None:
+            self.st["nonce"].copy_(torch.randint(0, 2 ** 62, (2,), dtype=torch.int64))
+        else:
+            self.st["nonce"].copy_(torch.tensor([int(nonce) * 0x9E3779B97F4A7C15 % (2 ** 62), 0], dtype=torch.int64))
 
     def _decode_step(self, B, use_forced=False, use_uniforms=False):
         cfg, st = self.cfg, self.st
@@ -387,7 +390,7 @@ class Qwen2LM:
     @torch.no_grad()
     def inference(self, text, text_len, prompt_text, prompt_text_len, prompt_speech_token, prompt_speech_token_len, embedding,
                   sampling: int = 25, max_token_text_ratio: float = 20, min_token_text_ratio: float = 2,
-                  lm_input: Optional[torch.Tensor] = None) -> Generator[int, None, None]:
+                  lm_input: Optional[torch.Tensor] = None, nonce: Optional[int] = None) -> Generator[int, None, None]:
         """Reference signature (llm.py:823-836).  Yields python ints as they become available (polled every 8 steps).
         ``lm_input`` (L, hidden): a ready-made prefill embedding sequence (see generate_batch)."""
         assert self._loaded
@@ -405,7 +408,7 @@ class Qwen2LM:
             raise ValueError("ctx_max too small for this request")
         st["min_len"].fill_(min_len)
         st["max_len"].fill_(max_len)
-        self._new_request_nonce()
+        self._new_request_nonce(nonce)
         self._assemble(ws, [text], [prompt_text], [prompt_speech_token], B, Lp, None if lm_input is None else [lm_input])
         self._prefill(B, Lp, False, False)
         sent, steps = 0, 1

@@ -57,15 +57,22 @@ class CosyVoice2Model:
         self.llm_loops = 2      # tts_batches: concurrent decode loops (each its own batch / KV caches) on those CUs
         self.llm_merge = 1      # tts_batches: consecutive batches decoded by ONE token loop (rows <= llm.max_batch)
         self.lock = threading.Lock()
-        # The reference's modules are re-entrant (every call builds its own activations / KV cache); here the stage objects own
-        # their KV caches, workspaces and captured graphs, so concurrent requests on ONE model object take turns per stage: a
-        # request holds llm_lock for its decode loop and flow_lock for each token2wav call (throughput across requests comes
-        # from tts_batch / tts_batches, which batch utterances instead of interleaving them).
-        self.llm_lock = threading.Lock()
+        # The reference's modules are re-entrant (every call builds its own activations / KV cache) and it interleaves requests:
+        # one LLM thread + side stream per tts() call (cli/model.py:62,119,189).  Here a decode loop owns KV caches, device state and
+        # captured graphs, so every request takes its OWN decode context over the one set of weights (Qwen2LM.new_context) from a
+        # pool of ``max_llm_requests`` and runs it on that context's stream: the token loops of concurrent requests overlap.  The
+        # flow / vocoder objects keep one workspace set: token2wav calls take turns (flow_lock) — they are GPU-bound, not
+        # latency-bound, so nothing is gained by interleaving them (batches go through tts_batch / tts_batches instead).
+        self.max_llm_requests = 4
+        self.llm_lock = threading.Lock()          # only for LMs without decode contexts (the v1 TransformerLM)
+        self._req_pool_lock = threading.Condition()
+        self._req_pool = None                     # [(context, stream)] free for requests
+        self._req_made = 0
         self.flow_lock = threading.Lock()
         self.tts_speech_token_dict = {}
         self.llm_end_dict = {}
         self.hift_cache_dict = {}
+        self._llm_spans = {}      # uuid -> [start, end] wall-clock of the request's token loop (diagnostics / tests)
 
     def load(self, llm_model, flow_model, hift_model):
         """model.py:71-81 — three flat state-dict files with the reference key names."""
@@ -80,7 +87,27 @@ class CosyVoice2Model:
         self.hift.load_state_dict(hift_sd)
         return self
 
-    def llm_job(self, text, prompt_text, llm_prompt_speech_token, llm_embedding, uuid_):
+    def _acquire_llm(self):
+        """A free (decode context, stream) pair for one request; grows the pool up to max_llm_requests, then waits."""
+        with self._req_pool_lock:
+            if self._req_pool is None:
+                self._req_pool = [(self.llm, self.llm_context.stream if hasattr(self.llm_context, "stream") else torch.cuda.Stream(self.device, priority=-1))]
+                self._req_made = 1
+            while True:
+                if self._req_pool:
+                    return self._req_pool.pop()
+                if self._req_made < self.max_llm_requests:
+                    self._req_made += 1
+                    break
+                self._req_pool_lock.wait()
+        return self.llm.new_context(), torch.cuda.Stream(self.device, priority=-1)
+
+    def _release_llm(self, pair):
+        with self._req_pool_lock:
+            self._req_pool.append(pair)
+            self._req_pool_lock.notify()
+
+    def llm_job(self, text, prompt_text, llm_prompt_speech_token, llm_embedding, uuid_, seed=None):
         # model.py:116-128.  The fork's phoneme LMs (Qwen2LM_Phoneme_Src2.inference, llm.py:1687-1699) take
         # text = (bpe ids, phoneme factors) and matching length tuples: tuples are passed through in that form.
         dev = self.device
@@ -91,15 +118,25 @@ class CosyVoice2Model:
         else:
             text_a, text_len = text.to(dev), torch.tensor([text.shape[1]], dtype=torch.int32)
             ptext_a, ptext_len = prompt_text.to(dev), torch.tensor([prompt_text.shape[1]], dtype=torch.int32)
-        with self.llm_lock, self.llm_context:
-            for i in self.llm.inference(text=text_a,
-                                        text_len=text_len,
-                                        prompt_text=ptext_a,
-                                        prompt_text_len=ptext_len,
-                                        prompt_speech_token=llm_prompt_speech_token.to(self.device),
-                                        prompt_speech_token_len=torch.tensor([llm_prompt_speech_token.shape[1]], dtype=torch.int32),
-                                        embedding=llm_embedding):
-                self.tts_speech_token_dict[uuid_].append(i)
+        kw = dict(text=text_a, text_len=text_len, prompt_text=ptext_a, prompt_text_len=ptext_len,
+                  prompt_speech_token=llm_prompt_speech_token.to(self.device),
+                  prompt_speech_token_len=torch.tensor([llm_prompt_speech_token.shape[1]], dtype=torch.int32), embedding=llm_embedding)
+        if hasattr(self.llm, "new_context"):
+            pair = self._acquire_llm()
+            try:
+                ctx, stream = pair
+                self._llm_spans[uuid_] = [time.perf_counter(), None]
+                with torch.cuda.stream(stream):
+                    for i in ctx.inference(nonce=seed, **kw):
+                        self.tts_speech_token_dict[uuid_].append(i)
+                    stream.synchronize()
+                self._llm_spans[uuid_][1] = time.perf_counter()
+            finally:
+                self._release_llm(pair)
+        else:
+            with self.llm_lock, self.llm_context:
+                for i in self.llm.inference(**kw):
+                    self.tts_speech_token_dict[uuid_].append(i)
         self.llm_end_dict[uuid_] = True
 
     def token2wav(self, *args, **kwargs):
@@ -149,7 +186,9 @@ class CosyVoice2Model:
         with self.lock:
             self.tts_speech_token_dict[this_uuid], self.llm_end_dict[this_uuid] = [], False
             self.hift_cache_dict[this_uuid] = None
-        p = threading.Thread(target=self.llm_job, args=(text, prompt_text, llm_prompt_speech_token, llm_embedding, this_uuid))
+        # ``seed`` (extra keyword, absent from the reference): Philox key material of this request's sampler; None draws it from
+        # torch's global generator (as the reference samples from the global RNG), an int makes the request reproducible
+        p = threading.Thread(target=self.llm_job, args=(text, prompt_text, llm_prompt_speech_token, llm_embedding, this_uuid, kwargs.get("seed")))
         p.start()
         if stream is True:
             self.flow.length_bucket = self.stream_length_bucket
@@ -227,7 +266,8 @@ class CosyVoice2Model:
         """Release what this model holds inside the HIP runtime (captured graphs of every stage / decode context, CU-masked
         streams) while the runtime is alive.  The model stays usable: graphs and streams are rebuilt on demand."""
         torch.cuda.synchronize()
-        for ctx in getattr(self, "_llm_contexts", None) or [self.llm]:
+        req_ctxs = [c for c, _ in (self._req_pool or [])]
+        for ctx in list(getattr(self, "_llm_contexts", None) or [self.llm]) + req_ctxs:
             for g in getattr(ctx, "_graphs", {}).values():
                 g.destroy()
             getattr(ctx, "_graphs", {}).clear()

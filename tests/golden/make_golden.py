@@ -647,11 +647,195 @@ def golden_flow_v1():
          est_x=x, est_mu=mu, est_cond=cond, est_spks=spks, est_t=t, est_out=est_out)
 
 
+# ----------------------------------------------------------------------------- round 2: full-depth / reference-loop goldens
+def _ref_lm_inference_capture(lm, text, prompt_text, prompt_speech, forced, eos):
+    """Drive the REFERENCE's own Qwen2LM.inference (llm/llm.py:823-874) teacher-forced: `forward_one_step` is wrapped to (a)
+    record the prefill sequence lm_input it receives on its first call and (b) hand HF a full-length attention mask (the
+    reference passes a current-chunk-length mask, llm.py:755,862; transformers 5.15 mis-reads that short mask at decode steps,
+    older releases ignore an all-ones mask = full causal attention over the cache, which is also what the reference's own
+    graph path does, qwen2_5.py:154-162); `sampling_ids` is replaced by a recorder that stores every log-prob row and returns
+    the forced id.  Everything else — the input assembly, llm_decoder, log_softmax, the loop bookkeeping — is the reference's."""
+    captured, rows = {}, []
+    enc = lm.llm
+
+    def fos(xs, masks, cache=None):
+        if "lm_input" not in captured:
+            captured["lm_input"] = xs.detach().clone()
+        past = 0 if cache is None else cache.get_seq_length()
+        outs = enc.model(inputs_embeds=xs, attention_mask=torch.ones(1, past + xs.shape[1], dtype=torch.bool),
+                         output_hidden_states=True, return_dict=True, use_cache=True, past_key_values=cache)
+        return outs.hidden_states[-1], outs.past_key_values
+
+    def recorder(weighted_scores, decoded_tokens, sampling, ignore_eos=True):
+        rows.append(weighted_scores.detach().clone())
+        i = len(decoded_tokens)
+        return torch.tensor([forced[i] if i < len(forced) else eos])
+
+    enc.forward_one_step, lm.sampling_ids = fos, recorder
+    with torch.inference_mode():
+        toks = list(lm.inference(text=text, text_len=torch.tensor([text.shape[1]]), prompt_text=prompt_text,
+                                 prompt_text_len=torch.tensor([prompt_text.shape[1]]), prompt_speech_token=prompt_speech,
+                                 prompt_speech_token_len=torch.tensor([prompt_speech.shape[1]]), embedding=torch.zeros(0, 192)))
+    assert toks == list(forced) and len(rows) == len(forced) + 1, (toks, len(rows))
+    return captured["lm_input"], torch.stack(rows)
+
+
+def golden_llm_loop():
+    """(a) tiny config: lm_input + teacher-forced log-probs through the reference's own inference() loop (supersedes the re-typed
+    assembly of golden_llm: the two must agree); (b) FULL size (24 layers, hidden 896, vocab 151 936): the same for 10 steps."""
+    from cosyvoice_amd.config import LlmConfig
+    from cosyvoice_amd.weights import llm_state_dict
+    for tag, cfg, n_text, n_pt, n_ps, n_forced in (("tiny", LlmConfig.tiny(), 6, 4, 9, 12), ("full", LlmConfig.full(), 12, 6, 30, 10)):
+        lm = build_ref_llm(cfg, llm_state_dict(cfg))
+        g = torch.Generator().manual_seed(31 if tag == "tiny" else 47)
+        text = torch.randint(0, cfg.vocab_size, (1, n_text), generator=g, dtype=torch.int32)
+        prompt_text = torch.randint(0, cfg.vocab_size, (1, n_pt), generator=g, dtype=torch.int32)
+        prompt_speech = torch.randint(0, cfg.speech_token_size, (1, n_ps), generator=g, dtype=torch.int32)
+        forced = torch.randint(0, cfg.speech_token_size, (n_forced,), generator=g).tolist()
+        lm_input, logps = _ref_lm_inference_capture(lm, text, prompt_text, prompt_speech, forced, cfg.speech_token_size)
+        save(f"llm_{tag}_loop", text=text, prompt_text=prompt_text, prompt_speech=prompt_speech, forced=np.array(forced),
+             lm_input=lm_input[0] if tag == "tiny" else lm_input[0, :, :64], lm_input_summary=summary(lm_input), logps=logps)
+        del lm
+
+
+def golden_sampler_ref():
+    """The reference's OWN sampling functions (utils/common.py:105-146: ras_sampling, non_random_ras_sampling, nucleus_sampling,
+    random_sampling) called as they are, with torch.Tensor.multinomial replaced by an inverse-CDF draw from recorded uniforms
+    (torch.multinomial's stream cannot be reproduced on another device): what is pinned is every decision around the draw —
+    the candidate set handed to multinomial, the repetition test, the fallback, the returned id."""
+    from cosyvoice.utils import common as C
+    g = torch.Generator().manual_seed(77)
+    V, n_cases = 300, 48
+    scores = torch.randn(n_cases, V, generator=g) * 2.5
+    scores[::7] *= 0.2                                    # flat rows: the top-k cap binds before top-p
+    uniforms = torch.rand(n_cases, 2, generator=g, dtype=torch.float64)
+    uniforms[::3, 0] *= 0.05                              # rows with a forced repetition draw the top candidate: fallback taken
+    hist = torch.randint(0, V, (n_cases, 12), generator=g)
+    calls = []
+    orig = torch.Tensor.multinomial
+
+    def fake_multinomial(self, num_samples, replacement=False, *, generator=None):
+        u = calls_state["u"][calls_state["k"]]
+        calls_state["k"] += 1
+        calls_state["inputs"].append(self.detach().clone())
+        c = torch.cumsum(self.double() / self.double().sum(), 0)
+        idx = int(torch.searchsorted(c, torch.tensor(u, dtype=torch.float64), right=True).item())
+        return torch.tensor([min(idx, self.numel() - 1)])
+
+    torch.Tensor.multinomial = fake_multinomial
+    out = {"ras": [], "nrras": [], "ras_n1": [], "nrras_n1": [], "ras_n2": [], "nrras_n2": []}
+    try:
+        for name, fn, kw in (("ras", C.ras_sampling, {}), ("nrras", C.non_random_ras_sampling, dict(top_k=10, expand_scale=2))):
+            for i in range(n_cases):
+                dec = hist[i].tolist()
+                if i % 3 == 0:      # force a repetition: the most likely id fills the window
+                    dec = dec[:2] + [int(scores[i].argmax())] * 10
+                calls_state = {"u": uniforms[i].tolist(), "k": 0, "inputs": []}
+                tid = fn(scores[i], dec, 25, **kw)
+                out[name].append(int(tid))
+                out[name + "_n1"].append(calls_state["inputs"][0].numel())
+                out[name + "_n2"].append(calls_state["inputs"][1].numel() if calls_state["k"] > 1 else 0)
+    finally:
+        torch.Tensor.multinomial = orig
+    dec_all = []
+    for i in range(n_cases):
+        dec = hist[i].tolist()
+        if i % 3 == 0:
+            dec = dec[:2] + [int(scores[i].argmax())] * 10
+        dec_all.append(dec)
+    save("sampler_ref", scores=scores, uniforms=uniforms, decoded=np.array(dec_all, dtype=np.int64),
+         **{k: np.array(v, dtype=np.int64) for k, v in out.items()})
+
+
+def golden_flow_full():
+    """FULL-depth reference flow (56 transformer blocks x 10 Euler steps, 6 + 4 conformer layers) on key-seeded weights at
+    T = 100 (prompt 15 + 35 tokens) and T = 500 (prompt 75 + 175 tokens: BASELINE C1's 3 s prompt), both with the encoder chunk
+    mask of CosyVoice2Model (static_chunk_size 50, cli/model.py:314) and with full attention (CosyVoiceModel wiring, :49-50)."""
+    from cosyvoice_amd.config import FlowConfig
+    from cosyvoice_amd.weights import flow_state_dict
+    cfg = FlowConfig.full()
+    flow = build_ref_flow(cfg, flow_state_dict(cfg))
+    g = torch.Generator().manual_seed(61)
+    out = {}
+    for tag, n_p, n_g in (("t100", 15, 35), ("t500", 75, 175)):
+        token = torch.randint(0, cfg.vocab_size, (1, n_g), generator=g, dtype=torch.int32)
+        prompt_token = torch.randint(0, cfg.vocab_size, (1, n_p), generator=g, dtype=torch.int32)
+        prompt_feat = torch.clamp(torch.randn(1, 2 * n_p, 80, generator=g) * 2 - 6, -11.5, 2.0)
+        embedding = torch.randn(1, cfg.spk_embed_dim, generator=g)
+        out.update({f"{tag}_token": token, f"{tag}_prompt_token": prompt_token, f"{tag}_prompt_feat": prompt_feat, f"{tag}_embedding": embedding})
+        for ctag, chunk in (("chunk50", 50), ("full", 0)):
+            flow.encoder.static_chunk_size = chunk
+            with torch.inference_mode():
+                mel, _ = flow.inference(token=token, token_len=torch.tensor([n_g]), prompt_token=prompt_token,
+                                        prompt_token_len=torch.tensor([n_p]), prompt_feat=prompt_feat,
+                                        prompt_feat_len=torch.tensor([2 * n_p]), embedding=embedding)
+            out[f"{tag}_mel_{ctag}"] = mel
+            out[f"{tag}_mel_{ctag}_chan_absmean"] = mel[0].abs().mean(dim=1)
+            print(tag, ctag, tuple(mel.shape), summary(mel))
+    save("flow_full", **out)
+
+
+def golden_stream_v2():
+    """The reference's own CosyVoice2Model (cli/model.py:295-424) streaming path: tts(stream=True) with a stub LLM that emits a
+    fixed token list and a stub vocoder that records the speech_feat / cache_source it is handed (the real HiFT draws random
+    source phases: its waveform is not comparable) and returns a deterministic "waveform" (each mel frame's mean repeated 480
+    times), so that the mel / source / speech caches, token_offset trimming and the hamming cross-fade of token2wav (:334-366)
+    all run as written.  With rand_noise fixed (flow_matching.py:212-213) every chunk's mel is deterministic."""
+    import threading  # noqa: F401
+    from cosyvoice.cli import model as ref_model
+    from cosyvoice_amd.config import FlowConfig
+    from cosyvoice_amd.weights import flow_state_dict
+    fc = FlowConfig.tiny()
+    flow = build_ref_flow(fc, flow_state_dict(fc))
+    g = torch.Generator().manual_seed(123)
+    n_tok, n_p = 137, 12                      # 137 = 2 full hops of 50 + 3 look-ahead ... + a 37-token tail
+    tokens = torch.randint(0, fc.vocab_size, (n_tok,), generator=g).tolist()
+    ptok = torch.randint(0, fc.vocab_size, (1, n_p), generator=g, dtype=torch.int32)
+    pfeat = torch.clamp(torch.randn(1, 2 * n_p, 80, generator=g) * 2 - 6, -11.5, 2.0)
+    emb = torch.randn(1, fc.spk_embed_dim, generator=g)
+
+    class StubLLM(torch.nn.Module):
+        fp16 = False
+
+        def inference(self, **kw):
+            for t in tokens:
+                yield t
+
+    calls = []
+
+    class StubHift(torch.nn.Module):
+        def inference(self, speech_feat, cache_source=torch.zeros(1, 1, 0)):
+            calls.append((speech_feat.detach().clone(), cache_source.detach().clone()))
+            wav = speech_feat.mean(dim=1).repeat_interleave(480, dim=1)           # (1, T * 480)
+            src = wav.unsqueeze(1) * 0.5
+            if cache_source.shape[2] != 0:                                        # generator.py:408-409
+                src[:, :, :cache_source.shape[2]] = cache_source
+            return wav, src
+
+    m = ref_model.CosyVoice2Model(StubLLM(), flow, StubHift(), fp16=False)
+    m.device = torch.device("cpu")
+    from contextlib import nullcontext
+    m.llm_context = nullcontext()
+    with torch.inference_mode():
+        chunks = [o["tts_speech"] for o in m.tts(text=torch.zeros(1, 5, dtype=torch.int32), flow_embedding=emb,
+                                                  flow_prompt_speech_token=ptok, prompt_speech_feat=pfeat, stream=True)]
+    out = {"tokens": np.array(tokens, dtype=np.int32), "prompt_token": ptok, "prompt_feat": pfeat, "embedding": emb,
+           "chunk_samples": np.array([c.shape[1] for c in chunks], dtype=np.int64), "n_calls": np.array(len(calls))}
+    for i, ((feat, src), c) in enumerate(zip(calls, chunks)):
+        out[f"feat{i}"] = feat          # the mel handed to the vocoder (cache frames prepended, token_offset trimmed)
+        out[f"src{i}"] = src[:, :, ::480] if src.shape[2] else src   # cache_source, one sample per frame (it is piecewise constant)
+        out[f"wav{i}"] = c[:, ::160]    # the yielded chunk after the cross-fade, decimated (keeps the fixture small)
+    print("stream chunks", out["chunk_samples"], "vocoder calls", len(calls))
+    save("stream_v2", **out)
+
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     install_stubs()
-    which = sys.argv[1:] or ["hift", "flow", "llm", "bigvgan", "frontend", "phoneme", "v1orch", "llmv1", "flowv1"]
+    which = sys.argv[1:] or ["hift", "flow", "llm", "bigvgan", "frontend", "phoneme", "v1orch", "llmv1", "flowv1", "llmloop", "samplerref",
+                             "flowfull", "streamv2"]
     if "hift" in which:
         golden_hift()
     if "flow" in which:
@@ -671,6 +855,14 @@ def main():
         golden_llm_v1()
     if "flowv1" in which:
         golden_flow_v1()
+    if "llmloop" in which:
+        golden_llm_loop()
+    if "samplerref" in which:
+        golden_sampler_ref()
+    if "flowfull" in which:
+        golden_flow_full()
+    if "streamv2" in which:
+        golden_stream_v2()
 
 
 if __name__ == "__main__":

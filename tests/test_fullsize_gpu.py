@@ -16,10 +16,11 @@ def full_flow():
     return cfg, flow_state_dict(cfg)
 
 
-@pytest.mark.parametrize("dt,l1_tol,linf_tol", [(torch.float16, 2.5e-3, 3e-2), (torch.bfloat16, 2.5e-2, 2.5e-1)])
+@pytest.mark.parametrize("dt,l1_tol,linf_tol", [(torch.float16, 1e-3, 1.5e-2), (torch.bfloat16, 1.2e-2, 1.5e-1)])
 def test_full_depth_flow_vs_oracle(full_flow, dt, l1_tol, linf_tol):
-    """north_star asks for mel L1 <= 1e-3 vs the fp32 reference; measured here for the full 56-block estimator x 10 Euler
-    steps with random (kaiming-scale) weights.  fp16 operands are what the bench uses."""
+    """north_star asks for mel L1 <= 1e-3 vs the fp32 reference: asserted for fp16 operands (what the bench uses; measured
+    8.1e-4) on the full 56-block estimator x 10 Euler steps with random (kaiming-scale) weights.  bf16 operands do NOT meet the
+    target (measured 5.7e-3, asserted at that level): BASELINE C2's "bf16" is reported in the bench as fp16 for that reason."""
     from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
     from oracle import flow as of
     cfg, sd = full_flow
@@ -61,7 +62,7 @@ def test_full_size_flow_properties_at_baseline_length(full_flow):
     assert torch.equal(mg, m)
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 2.5e-1), (torch.float16, 4e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 1.5e-1), (torch.float16, 4e-2)])
 def test_full_size_llm_logp_vs_oracle(dt, tol):
     """24 layers, hidden 896, 14/2 heads, vocab 151936: teacher-forced log-probs (prefill 40 + 6 decode steps) vs the oracle."""
     from cosyvoice_amd.llm import Qwen2LM

@@ -192,21 +192,34 @@ def test_tts_batches_merged_loops_free_running():
 
 
 @pytest.mark.gpu
-def test_concurrent_tts_requests_take_turns():
-    """Two request threads on ONE model object (the reference's server runtimes do this): the stage objects own their KV caches /
-    workspaces, so requests take turns per stage (llm_lock, flow_lock) and each gets exactly what it gets when run alone
-    (the sampler is seeded per request, so the token count — hence the waveform length — is reproducible)."""
+def test_concurrent_tts_requests_overlap_and_equal_solo_runs():
+    """Request threads on ONE model object, as the reference interleaves them (cli/model.py:62,119,189: one LLM thread + side
+    stream per tts() call): every request decodes on its own context (Qwen2LM.new_context), so the token loops run at the same
+    time, and a request seeded with ``seed=`` produces exactly the waveform it produces alone."""
     import threading
     m, lc, fc, hc = _model()
-    reqs = [_inputs(lc, fc, seed=s, n_text=n) for s, n in ((1, 4), (2, 7), (3, 5))]
-    alone = [sum(o["tts_speech"].shape[1] for o in m.tts(**r, stream=False)) for r in reqs]
+    reqs = [dict(_inputs(lc, fc, seed=s, n_text=n), seed=100 + s) for s, n in ((1, 9), (2, 11), (3, 10))]
+    # the vocoder's source noise comes from torch's global GPU generator, so waveforms are not comparable across runs: compare
+    # the token sequence every request hands to token2wav (recorded per calling thread) and the waveform length
+    seen, orig = {}, m.token2wav
+
+    def rec(*a, **kw):
+        seen[threading.get_ident()] = kw["token"].clone()
+        return orig(*a, **kw)
+    m.token2wav = rec
+
+    def one(r):
+        n = sum(o["tts_speech"].shape[1] for o in m.tts(**r, stream=False))
+        return seen[threading.get_ident()].flatten().tolist(), n
+    alone = [one(r) for r in reqs]
     got, errs = [None] * len(reqs), []
+    m._llm_spans.clear()
+    go = threading.Barrier(len(reqs))
 
     def run(i):
         try:
-            outs = list(m.tts(**reqs[i], stream=False))
-            assert all(torch.isfinite(o["tts_speech"]).all() for o in outs)
-            got[i] = sum(o["tts_speech"].shape[1] for o in outs)
+            go.wait()
+            got[i] = one(reqs[i])
         except Exception as e:      # surfaced in the main thread
             errs.append(e)
 
@@ -217,4 +230,31 @@ def test_concurrent_tts_requests_take_turns():
         t.join()
     assert not errs, errs
     assert got == alone
+    assert all(len(t) >= 18 for t, _ in got)
+    sp = sorted(v for v in m._llm_spans.values() if v[1] is not None)
+    assert len(sp) == len(reqs)
+    # the token loops overlap in time: the second one starts before the first one ends
+    assert sp[1][0] < sp[0][1], sp
     assert not m.tts_speech_token_dict and not m.llm_end_dict and not m.hift_cache_dict
+
+
+@pytest.mark.gpu
+def test_free_running_requests_differ_and_manual_seed_reproduces():
+    """The sampler's Philox key carries a per-request nonce drawn from torch's global generator: consecutive requests draw
+    different uniforms (the decode graph is NOT recaptured), torch.manual_seed reproduces a sequence of requests."""
+    m, lc, fc, hc = _model()
+    r = _inputs(lc, fc, seed=5, n_text=10)
+    def toks():
+        out = []
+        m.tts_speech_token_dict["x"], m.llm_end_dict["x"] = out, False
+        m.llm_job(r["text"], r["prompt_text"], r["llm_prompt_speech_token"], torch.zeros(0, 192), "x")
+        m.tts_speech_token_dict.pop("x"); m.llm_end_dict.pop("x")
+        return list(out)
+    torch.manual_seed(7)
+    a1, a2 = toks(), toks()
+    n_graphs = len(m.llm._graphs)
+    torch.manual_seed(7)
+    b1, b2 = toks(), toks()
+    assert a1 == b1 and a2 == b2
+    assert a1 != a2
+    assert len(m.llm._graphs) == n_graphs

@@ -207,3 +207,67 @@ def test_v1_flow_vs_reference(golden_dir):
         assert (cache2 - g["cache2"]).abs().max().item() < 1e-4
     print(f"v1 flow oracle vs reference: est {float((est - g['est_out']).abs().max()):.2e}, mel1 {float((mel1 - g['mel1']).abs().max()):.2e}, "
           f"mel2 {float((mel2 - g['mel2']).abs().max()):.2e}")
+
+
+# ----------------------------------------------------------------------------- round 2 goldens
+def test_llm_reference_inference_loop_tiny(golden_dir):
+    """The oracle against the fixture minted by driving the reference's OWN Qwen2LM.inference loop (lm_input captured at its
+    first forward_one_step, log-prob rows captured at sampling_ids): prefill assembly bit-equal, log-probs 1e-5; and the older
+    fixture (re-typed assembly) agrees with it."""
+    cfg = LlmConfig.tiny()
+    sd = llm_state_dict(cfg)
+    g = _load(golden_dir, "llm_tiny_loop")
+    lm_in = ol.build_lm_input(sd, cfg, g["text"], g["prompt_text"], g["prompt_speech"])
+    assert torch.equal(lm_in[0], g["lm_input"])
+    rows = []
+    list(ol.lm_inference(sd, cfg, g["text"], g["prompt_text"], g["prompt_speech"], uniforms=lambda t: (0.5, 0.5),
+                         forced_tokens=g["forced"].tolist(), collect_logp=rows))
+    assert (torch.stack(rows) - g["logps"]).abs().max().item() < 2e-5
+    old = _load(golden_dir, "llm_tiny")
+    assert torch.equal(old["forced"], g["forced"]) and (old["logps"] - g["logps"]).abs().max().item() < 1e-5
+
+
+def test_llm_reference_inference_loop_full_size(golden_dir):
+    """24 layers, hidden 896, vocab 151 936: 11 teacher-forced log-prob rows of the reference loop vs the oracle."""
+    cfg = LlmConfig.full()
+    sd = llm_state_dict(cfg)
+    g = _load(golden_dir, "llm_full_loop")
+    lm_in = ol.build_lm_input(sd, cfg, g["text"], g["prompt_text"], g["prompt_speech"])
+    assert torch.equal(lm_in[0, :, :64], g["lm_input"])
+    rows = []
+    with torch.inference_mode():
+        list(ol.lm_inference(sd, cfg, g["text"], g["prompt_text"], g["prompt_speech"], uniforms=lambda t: (0.5, 0.5),
+                             forced_tokens=g["forced"].tolist(), collect_logp=rows))
+    d = (torch.stack(rows) - g["logps"]).abs().max().item()
+    assert d < 5e-5, d
+
+
+def test_samplers_vs_reference_functions(golden_dir):
+    """oracle ras_sampling / non_random_ras_sampling against ids returned by the reference's own functions (utils/common.py:
+    105-146) with torch.multinomial replaced by an inverse-CDF draw from recorded uniforms."""
+    from oracle.llm_phoneme import non_random_ras_sampling
+    g = _load(golden_dir, "sampler_ref")
+    n = g["scores"].shape[0]
+    for i in range(n):
+        u = tuple(g["uniforms"][i].tolist())
+        dec = g["decoded"][i].tolist()
+        assert ol.ras_sampling(g["scores"][i], dec, u) == int(g["ras"][i]), i
+        assert non_random_ras_sampling(g["scores"][i], dec, u, top_k=10, expand_scale=2) == int(g["nrras"][i]), i
+        pc, _ = ol.nucleus_candidates(g["scores"][i])
+        assert pc.numel() == int(g["ras_n1"][i])
+    assert int((g["ras_n2"] > 0).sum()) >= n // 4 and int((g["nrras_n2"] > 0).sum()) >= n // 4   # the fallbacks are exercised
+
+
+@pytest.mark.parametrize("tag,chunk,key", [("t100", 50, "chunk50"), ("t500", 50, "chunk50"), ("t500", 0, "full")])
+def test_flow_full_depth_vs_reference(golden_dir, tag, chunk, key):
+    """FULL-depth oracle flow (56 estimator blocks x 10 Euler steps) vs the reference's mel at T = 100 / 500."""
+    cfg = FlowConfig.full()
+    sd = flow_state_dict(cfg)
+    g = _load(golden_dir, "flow_full")
+    with torch.inference_mode():
+        m = of.inference(sd, cfg, g[f"{tag}_token"], g[f"{tag}_prompt_token"], g[f"{tag}_prompt_feat"], g[f"{tag}_embedding"],
+                         static_chunk_size=chunk)
+    ref = g[f"{tag}_mel_{key}"]
+    d = (m - ref).abs()
+    assert d.max().item() < 2e-4 and d.mean().item() < 2e-5, (d.max().item(), d.mean().item())
+    assert (m[0].abs().mean(dim=1) - g[f"{tag}_mel_{key}_chan_absmean"]).abs().max().item() < 2e-5
