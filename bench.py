@@ -240,10 +240,18 @@ def main():
         w = run_steps(args.warmup)
         log(f"[rank {rank}] warmup: wav {tuple(w.shape)} absmax {w.abs().max().item():.3f}")
     fence()
+    model.pipeline_stats = [] if os.environ.get("CV_PIPELINE_STATS") else None
     t0 = time.perf_counter()
     run_steps(args.steps)
     fence()
     elapsed = cd.max_over_ranks(time.perf_counter() - t0, dev, dist)
+    if model.pipeline_stats:
+        for kind in ("llm", "flow"):
+            js = [(e - s_) * 1e3 / n for k, n, s_, e in model.pipeline_stats if k == kind]
+            log(f"[rank {rank}] pipeline {kind} jobs: " + " ".join(f"{j:.0f}" for j in js) + " ms per batch")
+        tmin = min(s_ for _, _, s_, _ in model.pipeline_stats)
+        log("timeline: " + " | ".join(f"{k}{n} {1e3*(s_-tmin):.0f}-{1e3*(e-tmin):.0f}" for k, n, s_, e in sorted(model.pipeline_stats, key=lambda x: x[2])))
+    model.pipeline_stats = None
 
     # what the collective layer saw: world size / backend of the process group and a SUM over ranks of the utterance counts
     dist_info = {"world_size": 1, "backend": None, "utterances_per_rank": [B], "utterances_total_allreduce": B}

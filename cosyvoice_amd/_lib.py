@@ -108,7 +108,7 @@ class TBlockParams(C.Structure):
         ("g3", _vp), ("b3n", _vp),
         ("w1_p", _vp), ("bf1", _vp),
         ("w2_p", _vp), ("bf2", _vp),
-        ("out_act", _vp), ("ldoa", _i32),
+        ("out_act", _vp), ("ldoa", _i32), ("cus", _i32),
     ]
 
 

@@ -39,7 +39,7 @@
 namespace {
 
 constexpr int TB_C = 256, TB_INNER = 512, TB_FF = 1024;
-constexpr int BM = 64;        // rows per workgroup (4 MFMA row tiles)
+constexpr int BM = 64;        // rows of the LDS operand images (LayerNorm / staging always cover 64 rows from the tile's first row)
 constexpr int NW = 8;         // waves per workgroup (two per SIMD)
 constexpr int NTHR = 64 * NW;
 constexpr int NS = 4;         // ring slots per wave, 8 fragments (8 KiB per wave) each
@@ -147,13 +147,15 @@ __device__ __forceinline__ void ln_rows_to_lds(const float* xs, int ldx, int t0,
 // groups w, w + 8, w + 16 (3 steps).  V steps swap the MFMA operands (D = xn . Wv^T has the frame index in the registers),
 // so a lane holds 4 consecutive frames of one (head, channel) row of V^T: 8-byte stores, no transposing pass.
 // Fragment group G = 4 step + k-quarter lives in ring slot G % 4 = k-quarter and is refilled with group G + 4 once computed.
-template <int DT, int ABL = 0>   // ABL: timing-only ablations (1: no output stores, 2: no ring refills)
+// MT = MFMA row tiles per workgroup (rows per tile 16 MT = 64 or 48): 48-row tiles exist for grids that would otherwise run as
+// two rounds with the second nearly empty (256 tiles of 64 rows on the 192 CUs the pipeline leaves the flow stage).
+template <int DT, int MT, int ABL = 0>   // ABL: timing-only ablations (1: no output stores, 2: no ring refills)
 __global__ __launch_bounds__(NTHR, 2) void tblock_head_kernel(const cv_tblock_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lq = lane & 15, lg = lane >> 4;
-  const int r = blockIdx.y, t0 = blockIdx.x * BM;
+  const int r = blockIdx.y, t0 = blockIdx.x * (16 * MT);
   const float* xs = p.x + (int64_t)r * p.T * p.ldx;
   constexpr int NKS = TB_C / 32;                       // 8 k-steps
   constexpr int NSTEP = 3 * TB_INNER / 16 / (4 * NW);  // 96 tiles / (8 waves x 4 tiles) = 3
@@ -179,18 +181,18 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_head_kernel(const cv_tblock_pa
   ld(s[3], 3);
   __syncthreads();
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[MT][4];
   auto compute = [&](uint4 (&sl)[8], int kq, bool vpart) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int ks = kq * 2 + u;
-      uint4 a[4];
+      uint4 a[MT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = *(const uint4*)(smem + (16 * i + lq) * 512 + (swz16(lq, ks * 4 + lg) << 4));
+      for (int i = 0; i < MT; ++i) a[i] = *(const uint4*)(smem + (16 * i + lq) * 512 + (swz16(lq, ks * 4 + lg) << 4));
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MT; ++i)
           acc[i][j] = vpart ? mfma_block<DT>(a[i], sl[j * 2 + u], acc[i][j]) : mfma_block<DT>(sl[j * 2 + u], a[i], acc[i][j]);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_head_kernel(const cv_tblock_pa
     constexpr int QK_STEPS = (2 * TB_INNER / 16) / (4 * NW);   // steps 0, 1: [Q | K] tiles for every wave; step 2: V tiles
     const bool vpart = st >= QK_STEPS;                         // compile-time after unrolling
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (!vpart) {
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_head_kernel(const cv_tblock_pa
       for (int kq = 0; kq < 4; ++kq) { compute(s[kq], kq, false); ld(s[kq], st * 4 + kq + NS); }
       // D rows = output column: lane holds row m = 16 i + lq, columns n .. n + 3
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < MT; ++i) {
         const int t = t0 + 16 * i + lq;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_head_kernel(const cv_tblock_pa
       for (int j = 0; j < 4; ++j) {
         const int vrow = (tile0 + j) * 16 + lq - 2 * TB_INNER;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MT; ++i) {
           const int t = t0 + 16 * i + 4 * lg;
           const uint2 u = pack4<DT>(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
           const int off = (vrow * p.vt_ld + t) * 2;
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_head_kernel(const cv_tblock_pa
         for (int j = 0; j < 4; ++j) {
           const int vrow = (tile0 + j) * 16 + lq - 2 * TB_INNER;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+          for (int i = 0; i < MT; ++i) {
             const int t = t0 + 16 * i + 4 * lg;
             const bool straddle = (t < p.T) && (t + 3 >= p.T);
 #pragma unroll
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_head_kernel(const cv_tblock_pa
 // (32 MFMAs): 4 out-projection groups (k-steps 4 g ..+3 of 16), then per chunk c the groups q = 0, 1 (hidden layer, k-steps
 // 4 q ..+3 of 8) and q = 2, 3 (output layer, k-steps 8 c + 4 (q - 2) ..+3 of 32).  Group G lives in ring slot G % 4 and its slot
 // is refilled with group G + 4 once computed.
-template <int DT, bool OUTPROJ, int ABL = 0>   // ABL: timing-only ablations (1: GELU -> identity, 2: no ring refills)
+template <int DT, bool OUTPROJ, int MT, int ABL = 0>   // ABL: timing-only ablations (1: GELU -> identity, 2: no ring refills)
 __global__ __launch_bounds__(NTHR, 2) void tblock_tail_kernel(const cv_tblock_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ximg = smem;
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_tail_kernel(const cv_tblock_pa
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lq = lane & 15, lg = lane >> 4;
-  const int r = blockIdx.y, t0 = blockIdx.x * BM;
+  const int r = blockIdx.y, t0 = blockIdx.x * (16 * MT);
   float* xs = p.x + (int64_t)r * p.T * p.ldx;
   const int ncol0 = wid * 32;
   constexpr int NC = TB_FF / HC;   // 4 chunks
@@ -316,10 +318,10 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_tail_kernel(const cv_tblock_pa
   };
 
   // residual rows in the accumulator layout (row 16 i + lq, columns ncol0 + 16 j + 4 lg ..+3)
-  f32x4_t acc2[4][2];
+  f32x4_t acc2[MT][2];
   auto load_residual = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MT; ++i) {
       const int t = min(t0 + 16 * i + lq, p.T - 1);
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc2[i][j] = *(const f32x4_t*)(xs + (int64_t)t * p.ldx + ncol0 + 16 * j + 4 * lg);
@@ -362,13 +364,13 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_tail_kernel(const cv_tblock_pa
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int ks = 4 * g + u;
-        uint4 a[4];
+        uint4 a[MT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = *(const uint4*)(smem + (16 * i + lq) * 1024 + (swz16(lq, ks * 4 + lg) << 4));
+        for (int i = 0; i < MT; ++i) a[i] = *(const uint4*)(smem + (16 * i + lq) * 1024 + (swz16(lq, ks * 4 + lg) << 4));
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc2[i][j] = mfma_block<DT>(sl[j * 4 + u], a[i], acc2[i][j]);
+          for (int i = 0; i < MT; ++i) acc2[i][j] = mfma_block<DT>(sl[j * 4 + u], a[i], acc2[i][j]);
       }
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -384,11 +386,11 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_tail_kernel(const cv_tblock_pa
       gam[j] = *(const float4*)(vecs + 256 + n);
       bet[j] = *(const float4*)(vecs + 512 + n);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { acc2[i][j][0] += bo.x; acc2[i][j][1] += bo.y; acc2[i][j][2] += bo.z; acc2[i][j][3] += bo.w; }
+      for (int i = 0; i < MT; ++i) { acc2[i][j][0] += bo.x; acc2[i][j][1] += bo.y; acc2[i][j][2] += bo.z; acc2[i][j][3] += bo.w; }
     }
-    float mean[4];
+    float mean[MT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MT; ++i) {
       float sm = 0.f;
 #pragma unroll
       for (int j = 0; j < 2; ++j) sm += (acc2[i][j][0] + acc2[i][j][1]) + (acc2[i][j][2] + acc2[i][j][3]);
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_tail_kernel(const cv_tblock_pa
     }
     __syncthreads();   // also: every wave is done reading the attention-output image
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MT; ++i) {
       const int m = 16 * i + lq;
       float sm = 0.f;
 #pragma unroll
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_tail_kernel(const cv_tblock_pa
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MT; ++i) {
       const int m = 16 * i + lq;
       float qs = 0.f;
 #pragma unroll
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_tail_kernel(const cv_tblock_pa
   for (int j = 0; j < 2; ++j) {
     const float4 b2 = *(const float4*)(vecs + 768 + ncol0 + 16 * j + 4 * lg);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { acc2[i][j][0] += b2.x; acc2[i][j][1] += b2.y; acc2[i][j][2] += b2.z; acc2[i][j][3] += b2.w; }
+    for (int i = 0; i < MT; ++i) { acc2[i][j][0] += b2.x; acc2[i][j][1] += b2.y; acc2[i][j][2] += b2.z; acc2[i][j][3] += b2.w; }
   }
   __syncthreads();   // xn image complete
 
@@ -451,24 +453,24 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_tail_kernel(const cv_tblock_pa
   for (int c = 0; c < NC; ++c) {
     char* hb = (c & 1) ? himg1 : himg0;
     // the accumulators of the hidden layer start from its bias (this wave's two tiles of the chunk)
-    f32x4_t acc1[4][2];
+    f32x4_t acc1[MT][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const float4 b1v = *(const float4*)(b1s + c * HC + (2 * wid + j) * 16 + 4 * lg);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc1[i][j] = f32x4_t{b1v.x, b1v.y, b1v.z, b1v.w};
+      for (int i = 0; i < MT; ++i) acc1[i][j] = f32x4_t{b1v.x, b1v.y, b1v.z, b1v.w};
     }
     auto compute_g1 = [&](uint4 (&sl)[8], int hf) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int ks = 4 * hf + u;
-        uint4 a[4];
+        uint4 a[MT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = *(const uint4*)(ximg + (16 * i + lq) * 512 + (swz16(lq, ks * 4 + lg) << 4));
+        for (int i = 0; i < MT; ++i) a[i] = *(const uint4*)(ximg + (16 * i + lq) * 512 + (swz16(lq, ks * 4 + lg) << 4));
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc1[i][j] = mfma_block<DT>(sl[j * 4 + u], a[i], acc1[i][j]);
+          for (int i = 0; i < MT; ++i) acc1[i][j] = mfma_block<DT>(sl[j * 4 + u], a[i], acc1[i][j]);
       }
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -476,13 +478,13 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_tail_kernel(const cv_tblock_pa
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int ks = 4 * hf + u;   // k-step inside the chunk (8 x 32 = 256 hidden columns)
-        uint4 a[4];
+        uint4 a[MT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = *(const uint4*)(hb + (16 * i + lq) * 512 + (swz16(lq, ks * 4 + lg) << 4));
+        for (int i = 0; i < MT; ++i) a[i] = *(const uint4*)(hb + (16 * i + lq) * 512 + (swz16(lq, ks * 4 + lg) << 4));
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc2[i][j] = mfma_block<DT>(sl[j * 4 + u], a[i], acc2[i][j]);
+          for (int i = 0; i < MT; ++i) acc2[i][j] = mfma_block<DT>(sl[j * 4 + u], a[i], acc2[i][j]);
       }
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_tail_kernel(const cv_tblock_pa
     compute_g1(s[1], 1); ld_ffn(s[1], 4 * c + 1 + NS);
     // GELU -> 16-bit chunk tile (row 16 i + lq, hidden columns (2 w + j) * 16 + 4 lg ..+3 of the chunk)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MT; ++i) {
       const int m = 16 * i + lq;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_tail_kernel(const cv_tblock_pa
   // ---- store the block output (fp32 residual stream, in place) + optional 16-bit copy (skip connection / next conv operand)
   uint16_t* oa = p.out_act ? (uint16_t*)p.out_act + (int64_t)r * p.T * p.ldoa : nullptr;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MT; ++i) {
     const int t = t0 + 16 * i + lq;
     if (t >= p.T) continue;
 #pragma unroll
@@ -533,31 +535,48 @@ template <typename K>
 void set_lds(K kern, size_t lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
 
 constexpr size_t TAIL_LDS = 98304 + 4096 + 4096 + 4096;
-template <int DT, bool OP, int ABL>
-void launch_tail(const cv_tblock_params& p, dim3 grid, hipStream_t st) {
+template <int DT, bool OP, int MT, int ABL>
+void launch_tail(const cv_tblock_params& p, hipStream_t st) {
   static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in
-  if (!attr_set) { set_lds(tblock_tail_kernel<DT, OP, ABL>, TAIL_LDS); attr_set = true; }
-  hipLaunchKernelGGL((tblock_tail_kernel<DT, OP, ABL>), grid, dim3(NTHR), TAIL_LDS, st, p);
+  if (!attr_set) { set_lds(tblock_tail_kernel<DT, OP, MT, ABL>, TAIL_LDS); attr_set = true; }
+  dim3 grid((p.T + 16 * MT - 1) / (16 * MT), p.R);
+  hipLaunchKernelGGL((tblock_tail_kernel<DT, OP, MT, ABL>), grid, dim3(NTHR), TAIL_LDS, st, p);
+}
+template <int DT, int MT, int ABL>
+void launch_head(const cv_tblock_params& p, hipStream_t st) {
+  dim3 grid((p.T + 16 * MT - 1) / (16 * MT), p.R);
+  hipLaunchKernelGGL((tblock_head_kernel<DT, MT, ABL>), grid, dim3(NTHR), 32768, st, p);
+}
+// rows per tile: the one that minimises (rounds of workgroups over the CUs the launch may use) x (rows per tile); one workgroup
+// per CU is resident.  p.cus = 0 means the whole chip.  CV_TBLOCK_MT=3|4 overrides (tuning aid).
+int pick_mt(const cv_tblock_params& p) {
+  static const int forced = env_int("CV_TBLOCK_MT", 0);
+  if (forced == 3 || forced == 4) return forced;
+  const int cus = p.cus > 0 ? p.cus : 256;
+  auto cost = [&](int mt) { const int wgs = p.R * ((p.T + 16 * mt - 1) / (16 * mt)); return (int64_t)((wgs + cus - 1) / cus) * mt; };
+  return cost(3) < cost(4) ? 3 : 4;
 }
 template <int DT>
-void dispatch_head(const cv_tblock_params& p, dim3 grid, hipStream_t st) {
+void dispatch_head(const cv_tblock_params& p, hipStream_t st) {
   if constexpr (DT == CV_F16) {   // timing-only ablation builds (wrong results): CV_TBLOCK_ABL=1|2|3
     static const int abl = env_int("CV_TBLOCK_ABL", 0);
-    if (abl == 1) { hipLaunchKernelGGL((tblock_head_kernel<DT, 1>), grid, dim3(NTHR), 32768, st, p); return; }
-    if (abl == 2) { hipLaunchKernelGGL((tblock_head_kernel<DT, 2>), grid, dim3(NTHR), 32768, st, p); return; }
-    if (abl == 3) { hipLaunchKernelGGL((tblock_head_kernel<DT, 3>), grid, dim3(NTHR), 32768, st, p); return; }
+    if (abl == 1) return launch_head<DT, 4, 1>(p, st);
+    if (abl == 2) return launch_head<DT, 4, 2>(p, st);
+    if (abl == 3) return launch_head<DT, 4, 3>(p, st);
   }
-  hipLaunchKernelGGL((tblock_head_kernel<DT, 0>), grid, dim3(NTHR), 32768, st, p);
+  if (pick_mt(p) == 3) launch_head<DT, 3, 0>(p, st);
+  else launch_head<DT, 4, 0>(p, st);
 }
 template <int DT, bool OP>
-void dispatch_tail(const cv_tblock_params& p, dim3 grid, hipStream_t st) {
+void dispatch_tail(const cv_tblock_params& p, hipStream_t st) {
   if constexpr (DT == CV_F16 && OP) {
     static const int abl = env_int("CV_TBLOCK_ABL", 0);
-    if (abl == 1) { launch_tail<DT, OP, 1>(p, grid, st); return; }
-    if (abl == 2) { launch_tail<DT, OP, 2>(p, grid, st); return; }
-    if (abl == 3) { launch_tail<DT, OP, 3>(p, grid, st); return; }
+    if (abl == 1) return launch_tail<DT, OP, 4, 1>(p, st);
+    if (abl == 2) return launch_tail<DT, OP, 4, 2>(p, st);
+    if (abl == 3) return launch_tail<DT, OP, 4, 3>(p, st);
   }
-  launch_tail<DT, OP, 0>(p, grid, st);
+  if (pick_mt(p) == 3) launch_tail<DT, OP, 3, 0>(p, st);
+  else launch_tail<DT, OP, 4, 0>(p, st);
 }
 
 }  // namespace
@@ -572,10 +591,9 @@ extern "C" int cv_tblock_head(const cv_tblock_params* pp, void* stream) {
   if ((p.ldqk & 3) || (p.vt_ld & 3) || p.vt_ld < p.T || ((uintptr_t)p.qk & 7) || ((uintptr_t)p.vt & 7) || ((uintptr_t)p.wqkv_p & 15))
     return CV_ERR_ARG;
   if ((int64_t)p.T * p.ldqk * 2 >= (1ll << 31) || (int64_t)TB_INNER * p.vt_ld * 2 >= 0x7FFFFFF0ll) return CV_ERR_ARG;   // 32-bit buffer offsets
-  dim3 grid((p.T + BM - 1) / BM, p.R);
   hipStream_t st = (hipStream_t)stream;
-  if (p.dtype == CV_BF16) dispatch_head<CV_BF16>(p, grid, st);
-  else dispatch_head<CV_F16>(p, grid, st);
+  if (p.dtype == CV_BF16) dispatch_head<CV_BF16>(p, st);
+  else dispatch_head<CV_F16>(p, st);
   CV_CHECK_LAUNCH();
   return CV_OK;
 }
@@ -589,10 +607,9 @@ extern "C" int cv_tblock_tail(const cv_tblock_params* pp, void* stream) {
   if (p.out_act && ((p.ldoa & 3) || ((uintptr_t)p.out_act & 7))) return CV_ERR_ARG;
   const bool outproj = p.ao != nullptr;
   if (outproj && (!p.wo_p || !p.bo || (p.ldao & 7) || ((uintptr_t)p.ao & 15) || ((uintptr_t)p.wo_p & 15))) return CV_ERR_ARG;
-  dim3 grid((p.T + BM - 1) / BM, p.R);
   hipStream_t st = (hipStream_t)stream;
-  if (p.dtype == CV_BF16) { if (outproj) dispatch_tail<CV_BF16, true>(p, grid, st); else dispatch_tail<CV_BF16, false>(p, grid, st); }
-  else { if (outproj) dispatch_tail<CV_F16, true>(p, grid, st); else dispatch_tail<CV_F16, false>(p, grid, st); }
+  if (p.dtype == CV_BF16) { if (outproj) dispatch_tail<CV_BF16, true>(p, st); else dispatch_tail<CV_BF16, false>(p, st); }
+  else { if (outproj) dispatch_tail<CV_F16, true>(p, st); else dispatch_tail<CV_F16, false>(p, st); }
   CV_CHECK_LAUNCH();
   return CV_OK;
 }

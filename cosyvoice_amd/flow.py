@@ -346,6 +346,7 @@ class ConditionalDecoder:
         if "wqkv_p" in tb and self.fused:
             # three launches: LN + [Q | K | V^T]  ->  flash attention  ->  to_out + residual + LN + FFN + residual
             p = ops.tblock_params(ws["x32"], R, T, 1e-5, self.dtype)
+            p.cus = int(getattr(self, "cu_budget", 0) or 0)   # CUs of the stream these launches go to (0 = all): tile-size choice only
             p.g1, p.b1n, p.wqkv_p = tb["g1"].data_ptr(), tb["b1"].data_ptr(), tb["wqkv_p"].data_ptr()
             p.qk, p.ldqk, p.vt, p.vt_ld = ws["qk"].data_ptr(), 2 * inner, ws["vt"].data_ptr(), Tp
             ops.tblock_head(p)
@@ -485,7 +486,7 @@ class CausalConditionalCFM:
             run()
             return x
         key = (B, T, n_timesteps, x.data_ptr(), mu.data_ptr(), spks.data_ptr(), cond.data_ptr(),
-               0 if klen2 is None else klen2.data_ptr())
+               0 if klen2 is None else klen2.data_ptr(), int(getattr(est, "cu_budget", 0) or 0), est.fused)
         g = self._graphs.get(key)
         if g is None:
             run()  # warm every lazily-built table outside capture

@@ -73,6 +73,7 @@ class CosyVoice2Model:
         self.llm_end_dict = {}
         self.hift_cache_dict = {}
         self._llm_spans = {}      # uuid -> [start, end] wall-clock of the request's token loop (diagnostics / tests)
+        self.pipeline_stats = None  # set to a list to collect (stage, batches, start, end) of every tts_batches job
 
     def load(self, llm_model, flow_model, hift_model):
         """model.py:71-81 — three flat state-dict files with the reference key names."""
@@ -334,6 +335,9 @@ class CosyVoice2Model:
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
         llm_parts, flow_part, borrow_part, prefill_parts = self.cu_partition(k, n_llm)
+        est = getattr(getattr(self.flow, "decoder", None), "estimator", None)
+        if est is not None:
+            est.cu_budget = (32 - k) * 8   # the flow's launches run on that many CUs: its row-block kernels size their tiles for it
         flow_full = torch.cuda.Stream(self.device)   # all CUs: the last batch's flow + HiFT run after every decode loop ended
         caller = torch.cuda.current_stream()
         ctxs = queue.Queue()
@@ -349,6 +353,7 @@ class CosyVoice2Model:
                 stream = borrow_part if borrow else own
                 cat = lambda key: [x for b in bs for x in b[key]]
                 forced = cat("forced") if all(b.get("forced") is not None for b in bs) else None
+                t_job = time.perf_counter()
                 with torch.no_grad(), torch.cuda.stream(stream):
                     stream.wait_event(ready)   # inputs the caller produced / the conditioning broadcast
                     # the prefill is throughput-bound GEMM work: it runs beside flow + HiFT on their (three times larger)
@@ -359,18 +364,24 @@ class CosyVoice2Model:
                 for b in bs:
                     out.append(toks[o:o + len(b["texts"])])
                     o += len(b["texts"])
+                if self.pipeline_stats is not None:   # generate_batch ends with a D2H of the token buffer: the loop is drained
+                    self.pipeline_stats.append(("llm", len(bs), t_job, time.perf_counter()))
                 return out
             finally:
                 ctxs.put((ctx, own, pf))
 
         def flow_job(b, llm_fut, idx, ready, stream):
             toks = llm_fut.result()[idx]
+            t_job = time.perf_counter()
             with torch.no_grad(), torch.cuda.stream(stream):
                 stream.wait_event(ready)
                 stream.wait_stream(flow_part if stream is flow_full else flow_full)  # workspaces of the previous batch
                 wav = self._flow_hift(b, toks)
                 if to_host:
-                    return ([w.cpu() for w in wav] if isinstance(wav, list) else wav.cpu()), None
+                    res = ([w.cpu() for w in wav] if isinstance(wav, list) else wav.cpu()), None
+                    if self.pipeline_stats is not None:
+                        self.pipeline_stats.append(("flow", 1, t_job, time.perf_counter()))
+                    return res
                 # the equal-length path returns a view of HiFT's per-shape workspace, which the next flow_job overwrites on this
                 # stream as soon as its tokens arrive: hand the consumer its own copy (made here, ordered before `done`)
                 wav = [w.clone() for w in wav] if isinstance(wav, list) else wav.clone()
@@ -410,6 +421,8 @@ class CosyVoice2Model:
                         inflight.append(flow_pool.submit(flow_job, b, lf, i, ready, flow_full if last else flow_part))
                     first = False
                 yield collect(inflight.popleft())
+        if est is not None:
+            est.cu_budget = 0
 
     @torch.no_grad()
     def _tts_batches_shared(self, batches, to_host):

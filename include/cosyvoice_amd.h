@@ -164,6 +164,8 @@ typedef struct cv_tblock_params {
   const void* w1_p; const float* bf1;     /* packed ff.net.0.proj (ff rows, K = C), bias [ff] */
   const void* w2_p; const float* bf2;     /* packed ff.net.2 (C rows, K = ff), bias [C] */
   void* out_act; int32_t ldoa;            /* optional 16-bit copy of the block output [R * T][ldoa] */
+  int32_t cus;                            /* CUs the launch may use (a CU-masked stream's share); 0 = the whole chip.  Speed only:
+                                             picks 48- or 64-row tiles so that the grid does not end in a nearly empty round */
 } cv_tblock_params;
 int cv_sizeof_tblock_params(void);
 int cv_tblock_head(const cv_tblock_params* p, void* stream);
