@@ -129,6 +129,21 @@ class SampleParams(C.Structure):
     ]
 
 
+class LlmLayer(C.Structure):
+    _fields_ = [("p_qkv", _vp), ("bqkv", _vp), ("p_o", _vp), ("p_gu", _vp), ("p_down", _vp), ("g_in", _vp), ("kcache", _vp), ("vtcache", _vp)]
+
+
+class LlmStepDesc(C.Structure):
+    _fields_ = [
+        ("dtype", _i32), ("B", _i32), ("num_layers", _i32), ("hidden", _i32), ("num_heads", _i32), ("num_kv_heads", _i32),
+        ("inter", _i32), ("ctx_max", _i32), ("down_ksplit", _i32), ("rms_eps", _f32),
+        ("layers", C.POINTER(LlmLayer)),
+        ("x", _vp), ("x2", _vp), ("xn", _vp), ("xb", _vp), ("ssp", _vp), ("n_ssp", _i32), ("qkv", _vp), ("ao", _vp), ("h", _vp),
+        ("slabs", _vp), ("logits", _vp), ("vpad", _i32), ("rope_table", _vp), ("g_final", _vp), ("p_dec", _vp), ("dec_b", _vp),
+        ("out_vocab", _i32), ("sample", SampleParams),
+    ]
+
+
 _lib = None
 
 
@@ -147,6 +162,10 @@ def lib():
             fn = getattr(_lib, f"cv_sizeof_{name}_params")
             if fn() != C.sizeof(st):
                 raise RuntimeError(f"ABI mismatch for cv_{name}_params: C {fn()} vs ctypes {C.sizeof(st)}")
+        for name, st in (("llm_step_desc", LlmStepDesc), ("llm_layer", LlmLayer)):
+            fn = getattr(_lib, f"cv_sizeof_{name}")
+            if fn() != C.sizeof(st):
+                raise RuntimeError(f"ABI mismatch for cv_{name}: C {fn()} vs ctypes {C.sizeof(st)}")
     return _lib
 
 
@@ -159,7 +178,8 @@ EXPORTS = ["cv_version", "cv_arch", "cv_gemm", "cv_layernorm", "cv_attention",
            "cv_decode_attention", "cv_sample_ras", "cv_sizeof_skinny_params", "cv_sizeof_sample_params", "cv_anti_alias_act", "cv_anti_alias_act_cl",
            "cv_stft_magnitude", "cv_log_clamp_channels_first", "cv_groupnorm_cl", "cv_groupnorm_workspace_floats",
            "cv_interp_linear_cl", "cv_sizeof_groupnorm_params", "cv_relpos_append", "cv_sizeof_tblock_params", "cv_tblock_head",
-           "cv_tblock_tail"]
+           "cv_tblock_tail", "cv_sizeof_llm_step_desc", "cv_sizeof_llm_layer", "cv_llm_step_enqueue", "cv_llm_step_graph_create",
+           "cv_llm_step_graph_launch", "cv_llm_step_graph_destroy"]
 
 TORCH_DT = {torch.float32: CV_F32, torch.bfloat16: CV_BF16, torch.float16: CV_F16}
 DT_TORCH = {v: k for k, v in TORCH_DT.items()}

@@ -55,6 +55,7 @@ class Qwen2LM:
         self.cu_budget = 0
         self.split_norm = os.environ.get("CV_SPLIT_NORM", "1") != "0"   # decode step: post-attention RMSNorm split over o_proj / gate-up
         self.use_graph = True
+        self.use_stage_abi = os.environ.get("CV_LLM_STAGE_ABI", "1") != "0"   # decode-step graph built by cv_llm_step_graph_create
         self._loaded = False
         self._graphs: Dict[int, ops.Graph] = {}
         self._prefill_ws: Dict[tuple, dict] = {}
@@ -142,6 +143,11 @@ class Qwen2LM:
         H = cfg.hidden_size
         ops.skinny_gemm(st["xn"], self.p_dec, B, cfg.out_vocab, H, bias=self.dec_b, out_f32=st["logits"], ldo=self.Vpad,
                         max_wgs=2 * self.cu_budget)
+        ops.sample_ras(self._sample_params(B, use_forced, use_uniforms))
+
+    def _sample_params(self, B, use_forced, use_uniforms):
+        cfg, st = self.cfg, self.st
+        H = cfg.hidden_size
         p = L.SampleParams()
         p.logits, p.ldl, p.V, p.B = st["logits"].data_ptr(), self.Vpad, cfg.out_vocab, B
         p.eos, p.top_k, p.top_p, p.win_size, p.tau_r = cfg.speech_token_size, self.top_k, self.top_p, self.win_size, self.tau_r
@@ -157,7 +163,32 @@ class Qwen2LM:
         p.emb_table, p.emb_dim = self.speech_embedding.data_ptr(), H
         p.x, p.ldx = st["x"].data_ptr(), H
         p.nonce = st["nonce"].data_ptr()
-        ops.sample_ras(p)
+        return p
+
+    def _step_desc(self, B, use_forced, use_uniforms):
+        """The decode step as ONE descriptor for the stage-level ABI (cv_llm_step_graph_create): every weight / state pointer of
+        the step.  The layer array is kept alive on the object (the library reads it at capture time only)."""
+        import ctypes as C
+        cfg, st = self.cfg, self.st
+        arr = (L.LlmLayer * cfg.num_layers)()
+        for i, lay in enumerate(self.layers):
+            a = arr[i]
+            a.p_qkv, a.bqkv, a.p_o, a.p_gu, a.p_down = (lay["p_qkv"].data_ptr(), lay["bqkv"].data_ptr(), lay["p_o"].data_ptr(),
+                                                        lay["p_gu_g"].data_ptr(), lay["p_down"].data_ptr())
+            a.g_in, a.kcache, a.vtcache = lay["g_in"].data_ptr(), self.kcache[i].data_ptr(), self.vtcache[i].data_ptr()
+        d = L.LlmStepDesc()
+        d.dtype, d.B, d.num_layers, d.hidden = L.TORCH_DT[self.dtype], B, cfg.num_layers, cfg.hidden_size
+        d.num_heads, d.num_kv_heads, d.inter, d.ctx_max = cfg.num_heads, cfg.num_kv_heads, cfg.intermediate_size, self.ctx_max
+        d.down_ksplit, d.rms_eps = self.DOWN_KSPLIT, cfg.rms_eps
+        d.layers = C.cast(arr, C.POINTER(L.LlmLayer))
+        d.x, d.x2, d.xn, d.xb = st["x"].data_ptr(), st["x2"].data_ptr(), st["xn"].data_ptr(), st["xb"].data_ptr()
+        d.ssp, d.n_ssp, d.qkv, d.ao, d.h = st["ssp"].data_ptr(), st["ssp"].shape[0], st["qkv"].data_ptr(), st["ao"].data_ptr(), st["h"].data_ptr()
+        d.slabs, d.logits, d.vpad = st["slabs"].data_ptr(), st["logits"].data_ptr(), self.Vpad
+        d.rope_table, d.g_final, d.p_dec, d.dec_b = self.rope_table.data_ptr(), self.g_final.data_ptr(), self.p_dec.data_ptr(), self.dec_b.data_ptr()
+        d.out_vocab = cfg.out_vocab
+        d.sample = self._sample_params(B, use_forced, use_uniforms)
+        d._keep = arr
+        return d
 
     def _new_request_nonce(self, nonce=None):
         """Fresh Philox key material for one request, drawn from torch's global (CPU) generator: consecutive requests and
@@ -223,10 +254,15 @@ class Qwen2LM:
             self._decode_step(B, use_forced, use_uniforms)
             return
         key = (B, use_forced, use_uniforms, self.seed, self.cu_budget, self.top_p, self.top_k, self.fallback_mode, self.top_p2, self.top_k2,
-               self.split_norm)
+               self.split_norm, self.use_stage_abi)
         g = self._graphs.get(key)
         if g is None:
-            g = ops.Graph().capture(lambda: self._decode_step(B, use_forced, use_uniforms))
+            if self.use_stage_abi and self.split_norm and self.DOWN_KSPLIT >= 2 and self.cu_budget == 0:
+                # the whole step composed and captured inside the library (cv_llm_step_graph_create): same launches as
+                # _decode_step, which stays as the eager path and as the cross-check of the C composition (tests)
+                g = ops.Graph.from_llm_step(self._step_desc(B, use_forced, use_uniforms))
+            else:
+                g = ops.Graph().capture(lambda: self._decode_step(B, use_forced, use_uniforms))
             self._graphs[key] = g
         g.launch()
 

@@ -331,6 +331,18 @@ class Graph:
         torch.cuda.current_stream().wait_stream(side)
         return self
 
+    @classmethod
+    def from_llm_step(cls, desc):
+        """Graph of one Qwen2 decode step, composed and captured by the library itself (cv_llm_step_graph_create)."""
+        self = cls()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            L.check(L.lib().cv_llm_step_graph_create(C.byref(desc), L.stream_ptr(), C.byref(self.handle)), "cv_llm_step_graph_create")
+        torch.cuda.current_stream().wait_stream(side)
+        self._desc = desc   # keeps the host-side layer array alive
+        return self
+
     def launch(self):
         """Replay on torch's current stream: as a hipGraphExec, or — when that stream is CU-masked (``masked_stream``) —
         launch by launch, because hipGraph replays ignore a stream's CU mask."""

@@ -338,6 +338,47 @@ typedef struct cv_sample_params {
   const uint64_t* nonce;
 } cv_sample_params;
 int cv_sample_ras(const cv_sample_params* p, void* stream);
+/* ------------------------------------------------------------------------------------------
+ * Stage-level entry points: a whole stage step behind one call, so that the composition of a stage does not
+ * live only in this package's Python classes.
+ * cv_llm_step_*: one decode step of the Qwen2 backbone for B <= 16 sequences — 24 x [RMSNorm + QKV -> RoPE + KV append +
+ * GQA attention -> o_proj (+ residual) -> RMSNorm -> gate/up + SwiGLU -> down (+ residual)] -> final norm -> llm_decoder ->
+ * repetition-aware sampling, loop bookkeeping and the next input embedding; positions / EOS state live on the device.
+ * Replaces the reference's graph decode path (llm/qwen2_5.py:97-179,265-320: four CUDA graphs per layer replayed from Python,
+ * positions on the host; llm/qwen2_infer.py:50-105) and the loop body of llm/llm.py:861-874.
+ * All pointers are caller-owned device buffers; `layers` is a host array read at enqueue / capture time only.
+ * cv_llm_step_enqueue issues the launches on `stream`; cv_llm_step_graph_create captures them (on `capture_stream`, which must
+ * not be the default stream) into a graph handle that cv_llm_step_graph_launch / cv_graph_launch_direct replay.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cv_llm_layer {
+  const void* p_qkv; const float* bqkv;   /* cv_pack_skinny([Wq; Wk; Wv]) (K = hidden), bias [q_dim + 2 kv_dim] fp32 */
+  const void* p_o;                        /* cv_pack_skinny(o_proj) (hidden rows, K = q_dim) */
+  const void* p_gu;                       /* cv_pack_skinny([gate; up] * post_attention_layernorm.weight, interleave = 1) */
+  const void* p_down;                     /* cv_pack_skinny(down_proj) (hidden rows, K = intermediate) */
+  const float* g_in;                      /* input_layernorm.weight [hidden] */
+  void* kcache; void* vtcache;            /* [B_max][Hkv][ctx_max][64], [B_max][Hkv][64][ctx_max] */
+} cv_llm_layer;
+typedef struct cv_llm_step_desc {
+  int32_t dtype, B, num_layers, hidden, num_heads, num_kv_heads, inter, ctx_max, down_ksplit; float rms_eps;
+  const cv_llm_layer* layers;             /* host array [num_layers] */
+  float* x; float* x2;                    /* [16][hidden] fp32: input embedding of the step / residual ping-pong */
+  void* xn; void* xb;                     /* [16][hidden] 16-bit scratch rows */
+  float* ssp; int32_t n_ssp;              /* [hidden / 16][16] partial sums of squares */
+  float* qkv;                             /* [16][q_dim + 2 kv_dim] fp32 */
+  void* ao; void* h;                      /* [16][q_dim], [16][inter] 16-bit */
+  float* slabs;                           /* [down_ksplit][16][hidden] fp32 */
+  float* logits; int32_t vpad;            /* [16][vpad] fp32 */
+  const float* rope_table;                /* [ctx_max][cos 32 | sin 32] */
+  const float* g_final; const void* p_dec; const float* dec_b; int32_t out_vocab;   /* model.norm, llm_decoder (packed), bias */
+  cv_sample_params sample;                /* sampler configuration + device state; logits / ldl / V / B / x / ldx / emb_dim are filled in */
+} cv_llm_step_desc;
+int cv_sizeof_llm_step_desc(void);
+int cv_sizeof_llm_layer(void);
+int cv_llm_step_enqueue(const cv_llm_step_desc* d, void* stream);
+int cv_llm_step_graph_create(const cv_llm_step_desc* d, void* capture_stream, void** graph_out);
+int cv_llm_step_graph_launch(void* graph, void* stream);
+int cv_llm_step_graph_destroy(void* graph);
+
 int cv_sizeof_gemm_params(void);
 int cv_sizeof_norm_params(void);
 int cv_sizeof_attn_params(void);

@@ -410,3 +410,29 @@ def test_generate_from_ready_made_prefill_embeddings():
         embs.append(torch.cat([sd["llm_embedding.weight"][0:1].float(), te, sd["llm_embedding.weight"][1:2].float(), pe], 0))
     got = lm.generate_batch(texts, ptexts, pspeech, uniforms=uni, lm_inputs=embs)
     assert got == want
+
+
+def test_stage_abi_step_equals_python_composed_step():
+    """cv_llm_step_graph_create (the decode step composed + captured inside the library) against the same step composed launch by
+    launch from Python: teacher-forced logits and free-running tokens (injected uniforms) bit-identical; the header's stage entry
+    points are what a non-Python host would bind."""
+    from cosyvoice_amd.llm import Qwen2LM
+    cfg = LlmConfig.tiny()
+    sd = llm_state_dict(cfg)
+    g = torch.Generator().manual_seed(3)
+    text = torch.randint(0, cfg.vocab_size, (1, 6), generator=g, dtype=torch.int32)
+    ptext = torch.randint(0, cfg.vocab_size, (1, 3), generator=g, dtype=torch.int32)
+    ps = torch.randint(0, cfg.speech_token_size, (1, 8), generator=g, dtype=torch.int32)
+    forced = torch.randint(0, cfg.speech_token_size, (9,), generator=g).tolist()
+    uni = torch.rand(16, 101, 2, generator=g) * 0.98
+    outs = {}
+    for abi in (True, False):
+        lm = Qwen2LM(cfg, dtype=torch.bfloat16, max_batch=4, ctx_max=256, max_out=256)
+        lm.use_stage_abi = abi
+        lm.load_state_dict(sd)
+        lp = lm.forced_logits(text, ptext, ps, forced).cpu()
+        toks = lm.generate_batch([text, text], [ptext, ptext], [ps, ps[:, :5]], uniforms=uni, max_steps=40)
+        outs[abi] = (lp, toks, len(lm._graphs))
+    assert torch.equal(outs[True][0], outs[False][0])
+    assert outs[True][1] == outs[False][1] and all(len(t) >= 10 for t in outs[True][1])
+    assert outs[True][2] >= 1
