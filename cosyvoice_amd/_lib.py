@@ -112,6 +112,19 @@ class TBlockParams(C.Structure):
     ]
 
 
+class ResblockParams(C.Structure):
+    _fields_ = [
+        ("dtype", _i32), ("R", _i32), ("T", _i32), ("C", _i32), ("cin", _i32),
+        ("a", _vp), ("lda", _i32),
+        ("w1_p", _vp), ("b1", _vp), ("g1", _vp), ("be1", _vp), ("tadd", _vp),
+        ("h1", _vp), ("ldh1", _i32),
+        ("w2_p", _vp), ("b2", _vp), ("g2", _vp), ("be2", _vp),
+        ("wr_p", _vp), ("br", _vp),
+        ("out", _vp), ("ldo", _i32),
+        ("eps", _f32), ("cus", _i32),
+    ]
+
+
 class SampleParams(C.Structure):
     _fields_ = [
         ("logits", _vp), ("ldl", _i32), ("V", _i32), ("B", _i32),
@@ -158,7 +171,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.cv_arch.restype = C.c_char_p
         for name, st in (("gemm", GemmParams), ("norm", NormParams), ("attn", AttnParams), ("skinny", SkinnyParams),
-                         ("sample", SampleParams), ("groupnorm", GroupNormParams), ("tblock", TBlockParams)):
+                         ("sample", SampleParams), ("groupnorm", GroupNormParams), ("tblock", TBlockParams), ("resblock", ResblockParams)):
             fn = getattr(_lib, f"cv_sizeof_{name}_params")
             if fn() != C.sizeof(st):
                 raise RuntimeError(f"ABI mismatch for cv_{name}_params: C {fn()} vs ctypes {C.sizeof(st)}")
@@ -179,7 +192,7 @@ EXPORTS = ["cv_version", "cv_arch", "cv_gemm", "cv_layernorm", "cv_attention",
            "cv_stft_magnitude", "cv_log_clamp_channels_first", "cv_groupnorm_cl", "cv_groupnorm_workspace_floats",
            "cv_interp_linear_cl", "cv_sizeof_groupnorm_params", "cv_relpos_append", "cv_sizeof_tblock_params", "cv_tblock_head",
            "cv_tblock_tail", "cv_sizeof_llm_step_desc", "cv_sizeof_llm_layer", "cv_llm_step_enqueue", "cv_llm_step_graph_create",
-           "cv_llm_step_graph_launch", "cv_llm_step_graph_destroy"]
+           "cv_llm_step_graph_launch", "cv_llm_step_graph_destroy", "cv_sizeof_resblock_params", "cv_resblock_conv1", "cv_resblock_conv2"]
 
 TORCH_DT = {torch.float32: CV_F32, torch.bfloat16: CV_BF16, torch.float16: CV_F16}
 DT_TORCH = {v: k for k, v in TORCH_DT.items()}

@@ -522,6 +522,241 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_tail_kernel(const cv_tblock_pa
   }
 }
 
+// ============================================================================================== causal resnet block
+// CausalResnetBlock1D of the estimator (flow/decoder.py:36-56, flow/components/decoder.py:54-59): two launches instead of five.
+//   conv1:  h1  = Mish(LayerNorm_C(causal_conv_k3(a) + b1)) + time_term                 (was: conv GEMM, layernorm)
+//   conv2:  out = Mish(LayerNorm_C(causal_conv_k3(h1) + b2)) + conv_1x1(a) + br         (was: conv GEMM, layernorm, 1x1 GEMM)
+// Same row-block structure as the transformer-block kernels: 8 waves on 16 MT rows, output columns split 8 ways (2 tiles per
+// wave), weights streamed once per workgroup through the 4-slot register ring, the LayerNorm over the 256 channels computed
+// from the accumulators.  The conv operand image holds rows t0 - 2 .. t0 + 16 MT + 1 of the input (channels-last), so the three
+// taps are the same image read at row offsets 0 / 1 / 2 (k = tap * cin + ci, the packed weight's K order); rows before the
+// sequence start are zeros (the causal left padding, flow/decoder.py:59-85).
+__device__ __forceinline__ float mish_fast(float x) {
+  // x tanh(softplus(x)) with tanh(log(1 + e^x)) = ((1 + e^x)^2 - 1) / ((1 + e^x)^2 + 1) = w / (w + 2), w = e^x (e^x + 2)
+  const float n = __builtin_amdgcn_exp2f(fminf(x, 20.f) * 1.4426950408889634f);
+  const float w = n * (n + 2.f);
+  return x * w * __builtin_amdgcn_rcpf(w + 2.f);
+}
+
+// rows [t_first, t_first + nrows) of a channels-last 16-bit tensor -> LDS operand image (pitch bytes per row, 16-byte chunk slots
+// swizzled by row & 15); rows outside [0, T) of the sequence: zeros before the start, the last row repeated beyond the end
+__device__ __forceinline__ void stage_rows(const uint16_t* src, int ld, int cin, int t_first, int nrows, int T, char* img, int pitch, int tid) {
+  const int cpr = cin >> 3;   // 16-byte chunks per row
+  const int total = nrows * cpr;
+  for (int id0 = 0; id0 < total; id0 += NTHR * 4) {
+    u32x4_t v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int id = min(id0 + u * NTHR + tid, total - 1);
+      const int row = id / cpr, ch = id - row * cpr;
+      const int t = t_first + row;
+      v[u] = *(const u32x4_t*)(src + (int64_t)min(max(t, 0), T - 1) * ld + ch * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int id = id0 + u * NTHR + tid;
+      if (id >= total) continue;
+      const int row = id / cpr, ch = id - row * cpr;
+      const bool zero = t_first + row < 0;
+      *(u32x4_t*)(img + row * pitch + (swz16(row, ch) << 4)) = zero ? u32x4_t{0u, 0u, 0u, 0u} : v[u];
+    }
+  }
+}
+
+// LayerNorm over the 256 channels of rows held in the accumulator layout (wave w: columns 32 w + 16 j + 4 lg ..+3): statistics
+// through `red` ([2][NW][64] floats).  On return acc holds (x - mean) * rstd * gamma + beta.  Two workgroup barriers.
+template <int MT>
+__device__ __forceinline__ void ln_acc(f32x4_t (&acc)[MT][2], float* red, const float* gam, const float* bet, float eps, int wid, int lq, int lg) {
+  float mean[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    float sm = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) sm += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+    sm += __shfl_xor(sm, 16, 64);
+    sm += __shfl_xor(sm, 32, 64);
+    if (lg == 0) red[wid * 64 + 16 * i + lq] = sm;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = 16 * i + lq;
+    float sm = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) sm += red[w * 64 + m];
+    mean[i] = sm * (1.0f / TB_C);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = acc[i][j][e] - mean[i]; acc[i][j][e] = d; q += d * d; }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    if (lg == 0) red[NW * 64 + wid * 64 + m] = q;
+  }
+  __syncthreads();
+  float4 g4[2], b4[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    g4[j] = *(const float4*)(gam + wid * 32 + 16 * j + 4 * lg);
+    b4[j] = *(const float4*)(bet + wid * 32 + 16 * j + 4 * lg);
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = 16 * i + lq;
+    float qs = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) qs += red[NW * 64 + w * 64 + m];
+    const float sc = rsqrtf(qs * (1.0f / TB_C) + eps);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      acc[i][j][0] = acc[i][j][0] * sc * g4[j].x + b4[j].x; acc[i][j][1] = acc[i][j][1] * sc * g4[j].y + b4[j].y;
+      acc[i][j][2] = acc[i][j][2] * sc * g4[j].z + b4[j].z; acc[i][j][3] = acc[i][j][3] * sc * g4[j].w + b4[j].w;
+    }
+  }
+}
+
+// STAGE 1: a (cin channels) -> h1;  STAGE 2: h1 (256 channels) + a -> out.  cin in {256, 320, 512}.
+// LDS: conv operand image at 0 (rows t0 - 2 ..., pitch round_up(K row bytes, 256)), stage 2's 1x1 operand image behind it,
+// then [2][NW][64] statistics and the staged vectors (bias | gamma | beta | time term or 1x1 bias).
+template <int DT, int STAGE, int MT>
+__global__ __launch_bounds__(NTHR, 2) void resblock_kernel(const cv_resblock_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lq = lane & 15, lg = lane >> 4;
+  const int r = blockIdx.y, t0 = blockIdx.x * (16 * MT);
+  const int cinc = STAGE == 1 ? p.cin : TB_C;                  // channels of the k3 conv's input
+  const int pitch = ((cinc * 2 + 255) >> 8) << 8;              // bytes per image row (>= 16 chunks, multiple of 16 chunks)
+  const int nrows = 16 * MT + 4;                               // t0 - 2 .. t0 + 16 MT + 1 (the last row only meets zero-padded k-steps)
+  char* cimg = smem;
+  const int pitch_a = ((p.cin * 2 + 255) >> 8) << 8;
+  char* aimg = smem + nrows * pitch;                           // STAGE 2: rows t0 .. of `a` for the 1x1 conv
+  float* red = (float*)(smem + nrows * pitch + (STAGE == 2 ? 16 * MT * pitch_a : 0));
+  float* vecs = red + 2 * NW * 64;                             // [4][256]
+  {
+    const float* v0 = STAGE == 1 ? p.b1 : p.b2;
+    const float* v1 = STAGE == 1 ? p.g1 : p.g2;
+    const float* v2 = STAGE == 1 ? p.be1 : p.be2;
+    const float* v3 = STAGE == 1 ? p.tadd : p.br;
+    vecs[tid] = tid < 256 ? v0[tid] : v1[tid - 256];
+    vecs[512 + tid] = tid < 256 ? v2[tid] : (v3 ? v3[tid - 256] : 0.f);
+  }
+  const int nks = (3 * cinc + 31) >> 5;          // k-steps of the k3 conv
+  const int nks_pad = (nks + 3) & ~3;            // the packed weights are zero-padded to whole groups of 4 k-steps
+  const int kpt = cinc >> 5;                     // k-steps per tap
+  const __amdgpu_buffer_rsrc_t wc_rs = frag_rsrc(STAGE == 1 ? p.w1_p : p.w2_p, 16 * nks_pad);
+  const int lane16 = lane * 16;
+  uint4 s[NS][8];
+  const int ngc = nks_pad >> 2;                  // groups of the k3 conv (2 tiles x 4 k-steps each)
+  const int nkr = p.cin >> 5, ngr = STAGE == 2 ? (nkr + 3) >> 2 : 0;   // 1x1 conv: k-steps, groups (weights zero-padded likewise)
+  const __amdgpu_buffer_rsrc_t wr_rs = frag_rsrc(STAGE == 2 ? p.wr_p : p.w1_p, 16 * (ngr > 0 ? ngr * 4 : 1));
+  // group G: conv groups 0 .. ngc - 1, then the 1x1 groups; beyond the end: harmless re-reads of the last group
+  auto ld = [&](uint4 (&sl)[8], int G) {
+    const int Gc = min(G, ngc + ngr - 1);
+    if (Gc < ngc) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sl[j * 4 + u] = frag_load(wc_rs, lane16, (2 * wid + j) * nks_pad + 4 * Gc + u);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sl[j * 4 + u] = frag_load(wr_rs, lane16, (2 * wid + j) * (ngr * 4) + 4 * (Gc - ngc) + u);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  ld(s[0], 0);
+  ld(s[1], 1);
+  const uint16_t* src = (const uint16_t*)(STAGE == 1 ? p.a : p.h1) + (int64_t)r * p.T * (STAGE == 1 ? p.lda : p.ldh1);
+  stage_rows(src, STAGE == 1 ? p.lda : p.ldh1, cinc, t0 - 2, nrows, p.T, cimg, pitch, tid);
+  if constexpr (STAGE == 2)
+    stage_rows((const uint16_t*)p.a + (int64_t)r * p.T * p.lda, p.lda, p.cin, t0, 16 * MT, p.T, aimg, pitch_a, tid);
+  ld(s[2], 2);
+  ld(s[3], 3);
+  __syncthreads();
+
+  f32x4_t acc[MT][2], accr[MT][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float4 b = *(const float4*)(vecs + wid * 32 + 16 * j + 4 * lg);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { acc[i][j] = f32x4_t{b.x, b.y, b.z, b.w}; accr[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  }
+  // k3 conv: k-step ks = tap * kpt + kc reads image row (16 i + lq + tap), chunk 4 kc + lg
+  for (int g0 = 0; g0 < ngc; g0 += NS) {
+#pragma unroll
+    for (int gg = 0; gg < NS; ++gg) {
+      const int g = g0 + gg;
+      if (g < ngc) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int ks = min(4 * g + u, nks - 1 + 0 * nks);   // padded k-steps (zero weights) re-read the last real one
+          const int tap = ks / kpt, kc = ks - tap * kpt;
+          uint4 a[MT];
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            const int row = 16 * i + lq + tap;
+            a[i] = *(const uint4*)(cimg + row * pitch + (swz16(row, kc * 4 + lg) << 4));
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i][j] = mfma_block<DT>(s[gg][j * 4 + u], a[i], acc[i][j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ld(s[gg], g + NS);
+      }
+    }
+  }
+  if constexpr (STAGE == 2) {
+    // 1x1 conv of the block input into its own accumulators; its groups continue the ring numbering at ngc
+    for (int g0 = 0; g0 < ngr; g0 += NS) {
+#pragma unroll
+      for (int gg = 0; gg < NS; ++gg) {
+        const int g = g0 + gg;             // 1x1 group index; ring slot (ngc + g) % NS
+        if (g < ngr) {
+          const int slot = (ngc + g) % NS;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int ks = min(4 * g + u, nkr - 1);
+            uint4 a[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = *(const uint4*)(aimg + (16 * i + lq) * pitch_a + (swz16(lq, ks * 4 + lg) << 4));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int i = 0; i < MT; ++i) {
+                // slot index must be a compile-time constant for the ring to stay in registers: select over the 4 slots
+                const uint4 wv = slot == 0 ? s[0][j * 4 + u] : (slot == 1 ? s[1][j * 4 + u] : (slot == 2 ? s[2][j * 4 + u] : s[3][j * 4 + u]));
+                accr[i][j] = mfma_block<DT>(wv, a[i], accr[i][j]);
+              }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+  ln_acc<MT>(acc, red, vecs + 256, vecs + 512, p.eps, wid, lq, lg);
+  // Mish, then the per-channel time term (stage 1) or the 1x1 conv + its bias (stage 2); store
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = wid * 32 + 16 * j + 4 * lg;
+    const float4 ad = *(const float4*)(vecs + 768 + n);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int t = t0 + 16 * i + lq;
+      float o0 = mish_fast(acc[i][j][0]) + ad.x, o1 = mish_fast(acc[i][j][1]) + ad.y;
+      float o2 = mish_fast(acc[i][j][2]) + ad.z, o3 = mish_fast(acc[i][j][3]) + ad.w;
+      if constexpr (STAGE == 2) { o0 += accr[i][j][0]; o1 += accr[i][j][1]; o2 += accr[i][j][2]; o3 += accr[i][j][3]; }
+      if (t >= p.T) continue;
+      if constexpr (STAGE == 1) *(uint2*)((uint16_t*)p.h1 + ((int64_t)r * p.T + t) * p.ldh1 + n) = pack4<DT>(o0, o1, o2, o3);
+      else *(float4*)(p.out + ((int64_t)r * p.T + t) * p.ldo + n) = make_float4(o0, o1, o2, o3);
+    }
+  }
+}
+
 int check_common(const cv_tblock_params& p) {
   if (p.dtype != CV_BF16 && p.dtype != CV_F16) return CV_ERR_UNSUPPORTED;
   if (p.C != TB_C || p.inner != TB_INNER || p.ff != TB_FF) return CV_ERR_UNSUPPORTED;
@@ -550,7 +785,7 @@ void launch_head(const cv_tblock_params& p, hipStream_t st) {
 // rows per tile: the one that minimises (rounds of workgroups over the CUs the launch may use) x (rows per tile); one workgroup
 // per CU is resident.  p.cus = 0 means the whole chip.  CV_TBLOCK_MT=3|4 overrides (tuning aid).
 int pick_mt(const cv_tblock_params& p) {
-  static const int forced = env_int("CV_TBLOCK_MT", 0);
+  const int forced = env_int("CV_TBLOCK_MT", 0);   // read per call: tests switch it
   if (forced == 3 || forced == 4) return forced;
   const int cus = p.cus > 0 ? p.cus : 256;
   auto cost = [&](int mt) { const int wgs = p.R * ((p.T + 16 * mt - 1) / (16 * mt)); return (int64_t)((wgs + cus - 1) / cus) * mt; };
@@ -612,4 +847,48 @@ extern "C" int cv_tblock_tail(const cv_tblock_params* pp, void* stream) {
   else { if (outproj) dispatch_tail<CV_F16, true>(p, st); else dispatch_tail<CV_F16, false>(p, st); }
   CV_CHECK_LAUNCH();
   return CV_OK;
+}
+
+namespace {
+template <int DT, int STAGE, int MT>
+int launch_resblock(const cv_resblock_params& p, hipStream_t st) {
+  const int cinc = STAGE == 1 ? p.cin : TB_C;
+  const int pitch = ((cinc * 2 + 255) >> 8) << 8, pitch_a = ((p.cin * 2 + 255) >> 8) << 8;
+  const size_t lds = (size_t)(16 * MT + 4) * pitch + (STAGE == 2 ? (size_t)16 * MT * pitch_a : 0) + 2 * NW * 64 * 4 + 4096;
+  if (lds > 160 * 1024) return CV_ERR_UNSUPPORTED;
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) { set_lds(resblock_kernel<DT, STAGE, MT>, 160 * 1024); attr_lds = 160 * 1024; }
+  dim3 grid((p.T + 16 * MT - 1) / (16 * MT), p.R);
+  hipLaunchKernelGGL((resblock_kernel<DT, STAGE, MT>), grid, dim3(NTHR), lds, st, p);
+  return hipGetLastError() == hipSuccess ? CV_OK : CV_ERR_LAUNCH;
+}
+template <int STAGE>
+int dispatch_resblock(const cv_resblock_params& p, hipStream_t st) {
+  cv_tblock_params q{};   // tile-size choice shared with the transformer-block kernels
+  q.R = p.R; q.T = p.T; q.cus = p.cus;
+  const bool mt3 = pick_mt(q) == 3;
+  if (p.dtype == CV_BF16) return mt3 ? launch_resblock<CV_BF16, STAGE, 3>(p, st) : launch_resblock<CV_BF16, STAGE, 4>(p, st);
+  return mt3 ? launch_resblock<CV_F16, STAGE, 3>(p, st) : launch_resblock<CV_F16, STAGE, 4>(p, st);
+}
+int check_resblock(const cv_resblock_params& p, int stage) {
+  if (p.dtype != CV_BF16 && p.dtype != CV_F16) return CV_ERR_UNSUPPORTED;
+  if (p.C != TB_C || (p.cin != 256 && p.cin != 320 && p.cin != 512)) return CV_ERR_UNSUPPORTED;
+  if (p.R <= 0 || p.T <= 0 || !p.a || (p.lda & 7) || p.lda < p.cin || ((uintptr_t)p.a & 15) || !p.h1 || (p.ldh1 & 7) || ((uintptr_t)p.h1 & 15)) return CV_ERR_ARG;
+  if (stage == 1 && (!p.w1_p || !p.b1 || !p.g1 || !p.be1 || ((uintptr_t)p.w1_p & 15))) return CV_ERR_ARG;
+  if (stage == 2 && (!p.w2_p || !p.b2 || !p.g2 || !p.be2 || !p.wr_p || !p.br || !p.out || (p.ldo & 3) || ((uintptr_t)p.out & 15) ||
+                     ((uintptr_t)p.w2_p & 15) || ((uintptr_t)p.wr_p & 15))) return CV_ERR_ARG;
+  return CV_OK;
+}
+}  // namespace
+
+extern "C" int cv_sizeof_resblock_params(void) { return (int)sizeof(cv_resblock_params); }
+extern "C" int cv_resblock_conv1(const cv_resblock_params* pp, void* stream) {
+  if (!pp) return CV_ERR_ARG;
+  if (int rc = check_resblock(*pp, 1)) return rc;
+  return dispatch_resblock<1>(*pp, (hipStream_t)stream);
+}
+extern "C" int cv_resblock_conv2(const cv_resblock_params* pp, void* stream) {
+  if (!pp) return CV_ERR_ARG;
+  if (int rc = check_resblock(*pp, 2)) return rc;
+  return dispatch_resblock<2>(*pp, (hipStream_t)stream);
 }

@@ -18,6 +18,7 @@ from typing import Dict, List, Optional
 
 import torch
 
+from . import _lib as L
 from . import ops
 from .config import FlowConfig
 
@@ -272,6 +273,15 @@ class ConditionalDecoder:
 
         names = [f"{prefix}down_blocks.0"] + [f"{prefix}mid_blocks.{i}" for i in range(cfg.est_mid_blocks)] + [f"{prefix}up_blocks.0"]
         self.blocks = [dict(res=resnet(f"{n}.0"), tb=[tblock(f"{n}.1.{j}") for j in range(cfg.est_n_blocks)]) for n in names]
+        if self.fused:
+            for blk in self.blocks:   # fragment-ordered conv weights of the row-block resnet kernels (K zero-padded to whole groups)
+                rs = blk["res"]
+                for k in ("w1", "w2", "wr"):
+                    w = rs[k]
+                    kp = _round_up(w.shape[1], 128)
+                    wp = torch.zeros(w.shape[0], kp, device=w.device, dtype=w.dtype)
+                    wp[:, :w.shape[1]] = w
+                    rs[k + "_p"] = ops.pack_skinny(wp)
         self.down_w, self.down_b = P.conv(f"{prefix}down_blocks.0.2.weight"), P.f32(f"{prefix}down_blocks.0.2.bias")
         self.up_w, self.up_b = P.conv(f"{prefix}up_blocks.0.2.weight"), P.f32(f"{prefix}up_blocks.0.2.bias")
         self.fin_w, self.fin_b = P.conv(f"{prefix}final_block.block.0.weight"), P.f32(f"{prefix}final_block.block.0.bias")
@@ -326,6 +336,20 @@ class ConditionalDecoder:
     def _resnet(self, rs, ws, R, a_in, lda, cin, tadd):
         C, T = self.cfg.est_channels, ws["T"]
         rows = R * T
+        if "w1_p" in rs and self.fused and cin in (256, 320, 512) and os.environ.get("CV_FLOW_FUSED_RESNET", "1") != "0":
+            # two row-block launches: conv + LayerNorm + Mish + time term | conv + LayerNorm + Mish + 1x1 conv of the input
+            p = L.ResblockParams()
+            p.dtype, p.R, p.T, p.C, p.cin = L.TORCH_DT[self.dtype], R, T, C, cin
+            p.a, p.lda = a_in.data_ptr(), lda
+            p.w1_p, p.b1, p.g1, p.be1, p.tadd = rs["w1_p"].data_ptr(), rs["b1"].data_ptr(), rs["g1"].data_ptr(), rs["be1"].data_ptr(), tadd.data_ptr()
+            p.h1, p.ldh1 = ws["h1"].data_ptr(), C
+            p.w2_p, p.b2, p.g2, p.be2 = rs["w2_p"].data_ptr(), rs["b2"].data_ptr(), rs["g2"].data_ptr(), rs["be2"].data_ptr()
+            p.wr_p, p.br = rs["wr_p"].data_ptr(), rs["br"].data_ptr()
+            p.out, p.ldo, p.eps = ws["x32"].data_ptr(), C, 1e-5
+            p.cus = int(getattr(self, "cu_budget", 0) or 0)
+            ops._issue("cv_resblock_conv1", p)
+            ops._issue("cv_resblock_conv2", p)
+            return
         kw = dict(batch=R, a_bs=(T * lda, 0), lda=lda, a_rows=T)
         c32a, c32b = ws["c32a"], ws["c32b"]
         ops.gemm(a_in, rs["w1"], T, C, 3 * cin, cin=cin, tap_base=-2, tap_step=1, bias=rs["b1"], out_f32=c32a,

@@ -172,6 +172,30 @@ int cv_tblock_head(const cv_tblock_params* p, void* stream);
 int cv_tblock_tail(const cv_tblock_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * cv_resblock_conv1 / cv_resblock_conv2 — CausalResnetBlock1D of the CFM estimator (flow/decoder.py:36-56 CausalBlock1D /
+ * CausalResnetBlock1D, flow/components/decoder.py:54-59 ResnetBlock1D.forward; CausalConv1d :59-85 = left padding k - 1) as
+ * two row-block kernels (same structure as cv_tblock_*):
+ *   conv1: h1  = Mish(LayerNorm_C(conv_k3(a) + b1)) + tadd            tadd [C] = mlp(mish(time embedding)) of this step / block
+ *   conv2: out = Mish(LayerNorm_C(conv_k3(h1) + b2)) + conv_1x1(a) + br
+ * a [R][T][lda] 16-bit channels-last (first cin channels), h1 [R][T][ldh1] 16-bit, out [R][T][ldo] fp32.  Weights packed by
+ * cv_pack_skinny from [C][K] matrices with k = tap * cin + ci (K zero-padded to a multiple of 128).  C = 256, cin in
+ * {256, 320, 512}; anything else returns CV_ERR_UNSUPPORTED (the caller keeps the cv_gemm / cv_layernorm launches).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct cv_resblock_params {
+  int32_t dtype, R, T, C, cin;
+  const void* a; int32_t lda;
+  const void* w1_p; const float* b1; const float* g1; const float* be1; const float* tadd;
+  void* h1; int32_t ldh1;
+  const void* w2_p; const float* b2; const float* g2; const float* be2;
+  const void* wr_p; const float* br;
+  float* out; int32_t ldo;
+  float eps; int32_t cus;
+} cv_resblock_params;
+int cv_sizeof_resblock_params(void);
+int cv_resblock_conv1(const cv_resblock_params* p, void* stream);
+int cv_resblock_conv2(const cv_resblock_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Layout / elementwise helpers (HBM-bound, coalesced, fp32 math).
  * ------------------------------------------------------------------------------------------ */
 /* x [B][C][T] fp32 (the reference's channel-first tensors) -> out [B][T][ldo] of `dtype` (channels-last; columns

@@ -148,3 +148,56 @@ def test_fused_estimator_equals_unfused(dt, tol, monkeypatch):
     d = (outs[0] - outs[1]).abs()
     print(f"fused vs unfused [{dt}]: Linf {d.max().item():.3e} L1 {d.mean().item():.3e} (values ~ {outs[1].abs().mean().item():.2f})")
     assert d.max().item() < tol * max(1.0, outs[1].abs().max().item())
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 6e-3), (torch.bfloat16, 5e-2)])
+@pytest.mark.parametrize("cin,T", [(320, 150), (256, 64), (512, 131)])
+def test_resblock_vs_torch(dt, tol, cin, T):
+    """cv_resblock_conv1 / conv2 (CausalResnetBlock1D: flow/decoder.py:36-56, components/decoder.py:54-59) against torch fp32 on the
+    same 16-bit-rounded operands: causal k3 conv -> LayerNorm over channels -> Mish (+ time term), twice, + 1x1 conv of the input."""
+    from cosyvoice_amd import _lib as L
+    from cosyvoice_amd import ops
+    g = torch.Generator().manual_seed(cin + T)
+    R, Cc = 2, 256
+    r = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    a = r(R, T, cin).to(dt)
+    w1, w2, wr = r(Cc, cin, 3, sc=(3 * cin) ** -0.5).to(dt), r(Cc, Cc, 3, sc=(3 * Cc) ** -0.5).to(dt), r(Cc, cin, 1, sc=cin ** -0.5).to(dt)
+    b1, b2, br = 0.1 * r(Cc), 0.1 * r(Cc), 0.1 * r(Cc)
+    g1, be1, g2, be2 = 1 + 0.1 * r(Cc), 0.1 * r(Cc), 1 + 0.1 * r(Cc), 0.1 * r(Cc)
+    tadd = 0.3 * r(Cc)
+
+    def causal_conv(x, w, b):   # x (R, T, Ci) -> (R, T, Co), left padding k - 1
+        k = w.shape[2]
+        return F.conv1d(F.pad(x.float().transpose(1, 2), (k - 1, 0)), w.float(), b).transpose(1, 2)
+    h = F.mish(F.layer_norm(causal_conv(a, w1, b1), (Cc,), g1, be1, 1e-5)) + tadd
+    h16 = h.to(dt)
+    ref = F.mish(F.layer_norm(causal_conv(h16, w2, b2), (Cc,), g2, be2, 1e-5)) + causal_conv(a, wr, br)
+
+    def packed(w):              # (Co, Ci, k) -> (Co, k * Ci) with k = tap * Ci + ci, K zero-padded to a multiple of 128
+        wm = w.permute(0, 2, 1).reshape(w.shape[0], -1)
+        kp = (wm.shape[1] + 127) // 128 * 128
+        wp = torch.zeros(w.shape[0], kp, dtype=dt)
+        wp[:, :wm.shape[1]] = wm
+        return ops.pack_skinny(wp.cuda().contiguous())
+    dv = lambda t: t.cuda().contiguous()
+    ad, h1d, outd = dv(a), torch.zeros(R, T, Cc, device="cuda", dtype=dt), torch.zeros(R, T, Cc, device="cuda")
+    keep = [packed(w1), packed(w2), packed(wr)] + [dv(t) for t in (b1, g1, be1, tadd, b2, g2, be2, br)]
+    p = L.ResblockParams()
+    p.dtype, p.R, p.T, p.C, p.cin = L.TORCH_DT[dt], R, T, Cc, cin
+    p.a, p.lda = ad.data_ptr(), cin
+    p.w1_p, p.b1, p.g1, p.be1, p.tadd = keep[0].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(), keep[5].data_ptr(), keep[6].data_ptr()
+    p.h1, p.ldh1 = h1d.data_ptr(), Cc
+    p.w2_p, p.b2, p.g2, p.be2 = keep[1].data_ptr(), keep[7].data_ptr(), keep[8].data_ptr(), keep[9].data_ptr()
+    p.wr_p, p.br = keep[2].data_ptr(), keep[10].data_ptr()
+    p.out, p.ldo, p.eps = outd.data_ptr(), Cc, 1e-5
+    for mt in ("4", "3"):
+        os.environ["CV_TBLOCK_MT"] = mt
+        h1d.zero_(); outd.zero_()
+        ops._issue("cv_resblock_conv1", p)
+        ops._issue("cv_resblock_conv2", p)
+        torch.cuda.synchronize()
+        e1 = (h1d.float().cpu() - h).abs().max().item()
+        e2 = (outd.cpu() - ref).abs().max().item()
+        print(f"resblock[{dt}, cin={cin}, T={T}, MT={mt}]: h1 Linf {e1:.3e}  out Linf {e2:.3e} (values ~ {ref.abs().mean().item():.2f})")
+        assert e1 < tol and e2 < tol
+    os.environ.pop("CV_TBLOCK_MT", None)
