@@ -11,6 +11,9 @@ LIB = os.path.join(HERE, "libcosyvoice_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Wno-unused-value",
          "-Wno-pass-failed"]
+# per-file additions.  attention.hip: no NaN is ever formed on its softmax path (masked scores are a large finite negative),
+# and without the flag every v_max on an MFMA result is preceded by a canonicalizing v_max(x, x).
+EXTRA_FLAGS = {"attention.hip": ["-fno-honor-nans"]}
 
 
 def _needs(obj, srcs):
@@ -24,7 +27,7 @@ def _compile(src):
     obj = src[:-4] + ".o"
     deps = [src] + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     if _needs(obj, deps):
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-8000:]))

@@ -8,6 +8,7 @@
 //   * V arrives pre-transposed (V^T [d][key], written by the QKV producer), so its A fragment is ONE 16-byte
 //     LDS read per lane from a [64 d][128 B] image with XOR-swizzled 16-byte chunk slots.
 // K / V^T tiles (64 keys) are staged through LDS, double-buffered with register prefetch (one barrier per tile).
+#include <type_traits>
 #include "cv_device.h"
 
 namespace {
@@ -18,12 +19,26 @@ constexpr int VT_BYTES = 64 * VT_PITCH;
 constexpr int STAGE_BYTES = KT_BYTES + VT_BYTES;
 constexpr float NEG_BIG = -1e30f;
 
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+// max over the four lanes that hold one query's scores (lane, lane^16, lane^32, lane^48): two v_permlane*_swap + v_max
+// instead of two ds_bpermute round trips through the LDS crossbar.
+__device__ __forceinline__ float xlane_max(float v) {
+  const uint32_t u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const uint32_t w = __float_as_uint(m);
+  const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 // launch bound 3 workgroups per CU (168 VGPRs, no spills): the kernel is stall-bound, not issue-bound (3 600 cycles per
 // tile-wave against ~900 of issue), so a third resident wave per SIMD bought 97 -> 83 us; a fourth needs 128 VGPRs and spills.
 template <int DT>
 __global__ __launch_bounds__(256, 3) void attn_kernel(const cv_attn_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform (tile counts and buffer soffsets derive from it)
   const int lq = lane & 15, lg = lane >> 4;
   // Key order inside a 64-key tile: row lq of S^T sub-tile kt is key krow(kt) = (kt>>1)*32 + (lq>>2)*8 + (kt&1)*4 + (lq&3), so
   // that the scores a lane holds for sub-tiles 2s and 2s+1 are 8 CONSECUTIVE keys (s*32 + lg*8 ..+7): P^T is then already
@@ -39,9 +54,11 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const cv_attn_params p) {
     kfrag0[kt] = (row << 7) + ((lg ^ kswz(row)) << 4);
     kfrag1[kt] = (row << 7) + (((4 + lg) ^ kswz(row)) << 4);
   }
-  const int b = blockIdx.z, h = blockIdx.y;
+  // grid = (heads, query blocks, batch): consecutive workgroup ids go round-robin over the 8 XCDs, so with heads fastest
+  // all query blocks of one (batch, head) run on ONE XCD and its K / V^T (256 KB at T = 1000) is fetched into one L2, not eight.
+  const int b = blockIdx.z, h = blockIdx.x;
   const int hk = h / (p.H / p.Hkv);
-  const int q_wg = blockIdx.x * 128;
+  const int q_wg = blockIdx.y * 128;
   const int q0 = q_wg + wid * 32;
 
   const uint16_t* Q = (const uint16_t*)p.q + (int64_t)b * p.q_bs + h * p.q_hs;
@@ -71,47 +88,53 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const cv_attn_params p) {
     }
   }
 
-  uint4 rk[2], rv[2];
-  int tile_j0 = 0;  // key offset of the prefetched tile: validity masks are applied when it is written to LDS, so the
-                    // loads stay in flight across the MFMA block (masking at load time would force the wait up here)
-  const int key_max = max(klen - 1, 0);
-  const int vchunk_max = max(((klen + 7) & ~7) - 8, 0);  // last 8-key chunk that holds a valid key (vt_ld % 8 == 0)
+  // K / V^T tile loads go through buffer descriptors: the per-thread offset is fixed, the tile offset is an SGPR (no
+  // per-tile address VALU), and K rows >= klen fall outside num_records and read as zeros (no clamp, no mask).
+  u32x4_t rk[2], rv[2];
+  int tile_j0 = 0;  // key offset of the prefetched tile (the V^T tail mask is applied when it is written to LDS)
+  const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)Kp, 0, klen > 0 ? ((klen - 1) * p.ldk + 64) * 2 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)Vt, 0, 64 * p.vt_ld * 2, 0x00020000);
+  int koff[2], voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = i * 256 + tid;
+    const int r = c >> 3, dc = c & 7;  // K: 8 consecutive lanes = one 128-byte key row; V^T: r = d row, dc = key chunk
+    koff[i] = (r * p.ldk + dc * 8) * 2;
+    voff[i] = (r * p.vt_ld + dc * 8) * 2;
+  }
   auto load_tile = [&](int t) {
     const int j0 = t << 6;
     tile_j0 = j0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int c = i * 256 + tid;
-      const int r = c >> 3, dc = c & 7;
-      const int kr = r, kdc = dc;  // K: 8 consecutive lanes = one 128-byte key row
-      rk[i] = *(const uint4*)(Kp + (int64_t)min(j0 + kr, key_max) * p.ldk + kdc * 8);
-      rv[i] = *(const uint4*)(Vt + (int64_t)r * p.vt_ld + min(j0 + dc * 8, vchunk_max));  // r = d row, dc = key chunk
+      rk[i] = __builtin_amdgcn_raw_buffer_load_b128(k_rs, koff[i], j0 * p.ldk * 2, 0);
+      rv[i] = __builtin_amdgcn_raw_buffer_load_b128(v_rs, voff[i], j0 * 2, 0);
     }
   };
   auto store_tile = [&](int s) {
     char* sk = smem + s * STAGE_BYTES;
     char* sv = sk + KT_BYTES;
+    const bool tail = tile_j0 + 64 > klen;  // wave-uniform: only the last tile of a sequence needs the V^T key mask
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = i * 256 + tid;
       const int r = c >> 3, dc = c & 7;
-      const int kr = r, kdc = dc;
-      const uint32_t km = (tile_j0 + kr < klen) ? 0xFFFFFFFFu : 0u;
-      *(uint4*)(sk + (kr << 7) + ((kdc ^ kswz(kr)) << 4)) =  // row-major, XOR-swizzled chunk slot
-          make_uint4(rk[i].x & km, rk[i].y & km, rk[i].z & km, rk[i].w & km);
-      // zero every key >= klen of the V^T chunk (0 * garbage must not become NaN)
-      const int nvalid = klen - (tile_j0 + dc * 8);
-      uint32_t u[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
+      *(u32x4_t*)(sk + (r << 7) + ((dc ^ kswz(r)) << 4)) = rk[i];  // row-major, XOR-swizzled chunk slot
+      u32x4_t u = rv[i];
+      if (tail) {  // zero every key >= klen of the V^T chunk (0 * garbage must not become NaN)
+        const int nvalid = klen - (tile_j0 + dc * 8);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const uint32_t m_lo = (2 * e < nvalid) ? 0x0000FFFFu : 0u;
-        const uint32_t m_hi = (2 * e + 1 < nvalid) ? 0xFFFF0000u : 0u;
-        u[e] &= (m_lo | m_hi);
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t m_lo = (2 * e < nvalid) ? 0x0000FFFFu : 0u;
+          const uint32_t m_hi = (2 * e + 1 < nvalid) ? 0xFFFF0000u : 0u;
+          u[e] &= (m_lo | m_hi);
+        }
       }
       // V^T image: 128-byte rows, chunk slot XOR (r >> 1) & 7 — 8 lanes fill one row (32 banks), the next 8 the other 32;
       // a fragment read (16 consecutive rows, one chunk) hits 8 distinct slots per bank half.  The padded 144-byte pitch it
       // replaces left 30 % of the kernel's LDS cycles as bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
-      *(uint4*)(sv + r * VT_PITCH + ((dc ^ ((r >> 1) & 7)) << 4)) = make_uint4(u[0], u[1], u[2], u[3]);
+      *(u32x4_t*)(sv + r * VT_PITCH + ((dc ^ ((r >> 1) & 7)) << 4)) = u;
     }
   };
 
@@ -120,7 +143,8 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const cv_attn_params p) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) oacc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float mrun[2] = {NEG_BIG, NEG_BIG}, lrun[2] = {0.f, 0.f};
+  float mrun[2] = {NEG_BIG, NEG_BIG};
+  f32x2_t lrun[2] = {f32x2_t{0.f, 0.f}, f32x2_t{0.f, 0.f}};
   const float sc = p.scale * 1.4426950408889634f;  // fold log2(e): softmax via exp2
 
   if (ntiles > 0) {
@@ -129,7 +153,11 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const cv_attn_params p) {
   }
   __syncthreads();
 
-  for (int t = 0; t < ntiles; ++t) {
+  // One 64-key tile.  MASKED = false is the interior version (every key of the tile visible to every query of the wave,
+  // no bias): no key-index compares, no limit arithmetic, no branches between the MFMA blocks.  Both versions end in the
+  // same single barrier, so waves of one workgroup may run different versions of the same tile.
+  auto tile = [&](auto masked_tag, const int t) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
     const int s = t & 1;
     if (t + 1 < ntiles) load_tile(t + 1);
     const char* sk = smem + s * STAGE_BYTES;
@@ -151,80 +179,88 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const cv_attn_params p) {
       }
     }
 
-    // ---- masks, online softmax (per query = per lane column).  The first version spent 730 VALU instructions per
-    // tile here (46 % of wave cycles, r01 PMC): now the max runs on raw scores (scale > 0 commutes with max), scale and
-    // max-subtraction fold into one fma feeding exp2, and interior tiles (every key below every query's limit) skip
-    // the per-element key-index compares altogether.
+    // ---- masks, online softmax (per query = per lane column).  r01 spent 730 VALU instructions per tile here, r02-a
+    // ~450 (ACTIVE_INST_ANY, PMC): now the max is a v_max3 chain on raw scores (scale > 0 commutes with max) reduced over
+    // lanes with two permlane swaps, scale and max-subtraction are packed fp32 FMAs feeding v_exp_f32, row sums and the
+    // alpha rescale are packed too.
     uint4 pf[2][2];
-    const bool has_bias = p.bias != nullptr;
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      const int i = q0 + qt * 16 + lq;
-      int jlim = klen;
-      if (p.causal) jlim = min(jlim, i + p.causal_off + 1);
-      if (p.chunk > 0) jlim = min(jlim, (i / p.chunk + 1) * p.chunk);
-      const bool tile_full = __all(j0 + 64 <= jlim);
       float mnew;
-      if (has_bias) {
-        const float* brow = p.bias + (int64_t)b * p.bias_bs + (int64_t)h * p.bias_hs + (int64_t)min(i, p.Tq - 1) * p.bias_ld;
-        float mx = NEG_BIG;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int j = j0 + ((kt >> 1) << 5) + (lg << 3) + ((kt & 1) << 2) + r;
-            float v = fmaf(sacc[kt][qt][r], sc, brow[min(j, p.Tk - 1)] * 1.4426950408889634f);
-            v = (j < jlim) ? v : NEG_BIG;
-            sacc[kt][qt][r] = v;
-            mx = fmaxf(mx, v);
-          }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        mnew = fmaxf(mrun[qt], mx);
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = __builtin_amdgcn_exp2f(sacc[kt][qt][r] - mnew);
-      } else {
-        if (!tile_full) {
+      bool dead = false;  // query with no visible key so far
+      if constexpr (MASKED) {
+        const int i = q0 + qt * 16 + lq;
+        int jlim = klen;
+        if (p.causal) jlim = min(jlim, i + p.causal_off + 1);
+        if (p.chunk > 0) jlim = min(jlim, (i / p.chunk + 1) * p.chunk);
+        if (p.bias != nullptr) {
+          const float* brow = p.bias + (int64_t)b * p.bias_bs + (int64_t)h * p.bias_hs + (int64_t)min(i, p.Tq - 1) * p.bias_ld;
 #pragma unroll
           for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int j = j0 + ((kt >> 1) << 5) + (lg << 3) + ((kt & 1) << 2) + r;
-              sacc[kt][qt][r] = (j < jlim) ? sacc[kt][qt][r] : NEG_BIG;
+              const float v = fmaf(sacc[kt][qt][r], sc, brow[min(j, p.Tk - 1)] * 1.4426950408889634f);
+              sacc[kt][qt][r] = (j < jlim) ? v : NEG_BIG;
+            }
+        } else {
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int j = j0 + ((kt >> 1) << 5) + (lg << 3) + ((kt & 1) << 2) + r;
+              sacc[kt][qt][r] = (j < jlim) ? sacc[kt][qt][r] * sc : NEG_BIG;
             }
         }
-        float mx = fmaxf(fmaxf(sacc[0][qt][0], sacc[0][qt][1]), fmaxf(sacc[0][qt][2], sacc[0][qt][3]));
-#pragma unroll
-        for (int kt = 1; kt < 4; ++kt)
-          mx = fmaxf(mx, fmaxf(fmaxf(sacc[kt][qt][0], sacc[kt][qt][1]), fmaxf(sacc[kt][qt][2], sacc[kt][qt][3])));
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        mnew = fmaxf(mrun[qt], mx * sc);  // a fully masked slice gives NEG_BIG * sc: still far below any real score
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = __builtin_amdgcn_exp2f(fmaf(sacc[kt][qt][r], sc, -mnew));
       }
-      // a query with no visible key so far (negative causal_off, klen 0): every masked score equals the running "max", exp2(0) = 1
-      // would count the masked keys.  Zero the probabilities while the running max is still the mask value: the row ends as zeros.
-      if (mnew <= 0.5f * NEG_BIG * fminf(sc, 1.0f)) {
+      // 16 in-lane scores -> v_max3 chains (the file is built with -fno-honor-nans: no canonicalize per operand)
+      float mx = fmaxf(fmaxf(sacc[0][qt][0], sacc[0][qt][1]), sacc[0][qt][2]);
+      mx = fmaxf(fmaxf(mx, sacc[0][qt][3]), sacc[1][qt][0]);
+      mx = fmaxf(fmaxf(mx, sacc[1][qt][1]), sacc[1][qt][2]);
+      float my = fmaxf(fmaxf(sacc[1][qt][3], sacc[2][qt][0]), sacc[2][qt][1]);
+      my = fmaxf(fmaxf(my, sacc[2][qt][2]), sacc[2][qt][3]);
+      my = fmaxf(fmaxf(my, sacc[3][qt][0]), sacc[3][qt][1]);
+      my = fmaxf(fmaxf(my, sacc[3][qt][2]), sacc[3][qt][3]);
+      mx = xlane_max(fmaxf(mx, my));
+      // interior tiles hold raw scores (scale folded into the FMA below), masked tiles hold scaled ones
+      const float scl = MASKED ? 1.0f : sc;
+      mnew = fmaxf(mrun[qt], mx * scl);
+      if constexpr (MASKED) dead = mnew <= 0.5f * NEG_BIG;
+      const f32x2_t sc2 = f32x2_t{scl, scl}, nm2 = f32x2_t{-mnew, -mnew};
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) sacc[kt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int kt = 0; kt < 4; ++kt) {
+        const f32x2_t lo = f32x2_t{sacc[kt][qt][0], sacc[kt][qt][1]} * sc2 + nm2;
+        const f32x2_t hi = f32x2_t{sacc[kt][qt][2], sacc[kt][qt][3]} * sc2 + nm2;
+        // v_exp_f32 directly (exp2f's denormal handling costs four more VALU per element; a flushed 2^-127 is 0 here anyway)
+        sacc[kt][qt][0] = __builtin_amdgcn_exp2f(lo[0]);
+        sacc[kt][qt][1] = __builtin_amdgcn_exp2f(lo[1]);
+        sacc[kt][qt][2] = __builtin_amdgcn_exp2f(hi[0]);
+        sacc[kt][qt][3] = __builtin_amdgcn_exp2f(hi[1]);
       }
-      // v_exp_f32 directly (exp2f's denormal handling costs four more VALU per element; a flushed 2^-127 is 0 here anyway)
+      if constexpr (MASKED) {
+        // a query with no visible key so far (negative causal_off, klen 0): every masked score equals the running "max" and
+        // exp2(0) = 1 would count the masked keys.  Zero the probabilities while the running max is still the mask value: the
+        // row ends as zeros.  (An interior tile cannot hold such a row.)
+        if (dead) {
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) sacc[kt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+      }
       const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
       const bool same_max = __all(mnew == mrun[qt]);  // running max unchanged for every query of the wave: alpha == 1
       mrun[qt] = mnew;
-      float ls = 0.f;
+      f32x2_t ls = f32x2_t{sacc[0][qt][0], sacc[0][qt][1]} + f32x2_t{sacc[0][qt][2], sacc[0][qt][3]};
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) ls += (sacc[kt][qt][0] + sacc[kt][qt][1]) + (sacc[kt][qt][2] + sacc[kt][qt][3]);
-      lrun[qt] = lrun[qt] * alpha + ls;
+      for (int kt = 1; kt < 4; ++kt)
+        ls += f32x2_t{sacc[kt][qt][0], sacc[kt][qt][1]} + f32x2_t{sacc[kt][qt][2], sacc[kt][qt][3]};
+      const f32x2_t al2 = f32x2_t{alpha, alpha};
+      lrun[qt] = lrun[qt] * al2 + ls;
       if (!same_max) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          oacc[dt][qt][0] *= alpha; oacc[dt][qt][1] *= alpha; oacc[dt][qt][2] *= alpha; oacc[dt][qt][3] *= alpha;
+          const f32x2_t lo = f32x2_t{oacc[dt][qt][0], oacc[dt][qt][1]} * al2;
+          const f32x2_t hi = f32x2_t{oacc[dt][qt][2], oacc[dt][qt][3]} * al2;
+          oacc[dt][qt] = f32x4_t{lo[0], lo[1], hi[0], hi[1]};
         }
       }
       // P^T fragments: k-step s2 = sub-tiles 2*s2 (elements 0..3) and 2*s2+1 (elements 4..7) = keys s2*32 + lg*8 ..+7
@@ -255,13 +291,25 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const cv_attn_params p) {
 
     if (t + 1 < ntiles) store_tile(s ^ 1);
     __syncthreads();
+  };
+
+  // interior tiles of this wave: all 64 keys below the limit of its first (= most restricted) query, and no bias
+  int nfull = 0;
+  if (p.bias == nullptr) {
+    int jmin = klen;
+    if (p.causal) jmin = min(jmin, q0 + p.causal_off + 1);
+    if (p.chunk > 0) jmin = min(jmin, (q0 / p.chunk + 1) * p.chunk);
+    nfull = min(max(jmin, 0) >> 6, ntiles);
   }
+  int t = 0;
+  for (; t < nfull; ++t) tile(std::false_type{}, t);
+  for (; t < ntiles; ++t) tile(std::true_type{}, t);
 
   // ---- finalize: O[q][d] = O^T / l ; lane holds q = lq, d = dt*16 + 4*lg + r
   uint16_t* O = (uint16_t*)p.out + (int64_t)b * p.o_bs + h * 64;
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    float l = lrun[qt];
+    float l = lrun[qt][0] + lrun[qt][1];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float inv = l > 0.f ? 1.0f / l : 0.f;
@@ -291,7 +339,7 @@ extern "C" int cv_attention(const cv_attn_params* pp, void* stream) {
   if ((p.ldq & 7) || (p.ldk & 7) || (p.vt_ld & 7) || (p.ldo & 3) || (p.q_bs & 7) || (p.k_bs & 7) || (p.o_bs & 3)) return CV_ERR_ARG;
   if (p.vt_ld < p.Tk) return CV_ERR_ARG;
   if (((uintptr_t)p.q & 15) || ((uintptr_t)p.k & 15) || ((uintptr_t)p.vt & 15) || ((uintptr_t)p.out & 7)) return CV_ERR_ARG;
-  dim3 grid((p.Tq + 127) / 128, p.H, p.B);
+  dim3 grid(p.H, (p.Tq + 127) / 128, p.B);
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = 2 * STAGE_BYTES;
   if (p.dtype == CV_BF16) hipLaunchKernelGGL(attn_kernel<CV_BF16>, grid, dim3(256), lds, st, p);

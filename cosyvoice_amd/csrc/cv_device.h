@@ -33,9 +33,16 @@ template <> struct Elem16<CV_F16> {
   static __device__ __forceinline__ float to_f32(uint16_t u) { return (float)bitcast<_Float16>(u); }
 };
 
+// two fp32 -> one packed 16-bit pair, RNE: ONE instruction on gfx950 (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32); the scalar
+// casts compile to cvt + cvt_sdwa + or for fp16.
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 template <int DT>
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
-  return (uint32_t)Elem16<DT>::from_f32(a) | ((uint32_t)Elem16<DT>::from_f32(b) << 16);
+  const f32x2_t v = f32x2_t{a, b};
+  if constexpr (DT == CV_BF16) return bitcast<uint32_t>(__builtin_convertvector(v, bf16x2_t));
+  else return bitcast<uint32_t>(__builtin_convertvector(v, f16x2_t));
 }
 
 // One "block" MFMA step over the K extent of four 16-byte chunks (32 k for 16-bit, 16 k for f32).
