@@ -144,8 +144,8 @@ def ev_time(fn, n, warm=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=32)   # 32 pipelined passes (~5 s): fill + drain (~0.5 s) stay inside the timed region
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the stage / C2 / C3 measurements (tuning runs)")
     ap.add_argument("--flow-dtype", default="fp16", choices=["fp16", "bf16"])

@@ -188,7 +188,7 @@ EXPORTS = ["cv_version", "cv_arch", "cv_gemm", "cv_layernorm", "cv_attention",
            "cv_embedding", "cv_est_pack", "cv_cfm_update", "cv_graph_begin", "cv_graph_end", "cv_graph_launch",
            "cv_graph_destroy", "cv_graph_launch_direct", "cv_graph_num_launches", "cv_stream_create_cumask",
            "cv_stream_destroy", "cv_skinny_gemm", "cv_pack_skinny", "cv_rmsnorm_reduce", "cv_rope_append",
-           "cv_decode_attention", "cv_sample_ras", "cv_sizeof_skinny_params", "cv_sizeof_sample_params", "cv_anti_alias_act", "cv_anti_alias_act_cl",
+           "cv_decode_attention", "cv_kv_retile", "cv_sample_ras", "cv_sizeof_skinny_params", "cv_sizeof_sample_params", "cv_anti_alias_act", "cv_anti_alias_act_cl",
            "cv_stft_magnitude", "cv_log_clamp_channels_first", "cv_groupnorm_cl", "cv_groupnorm_workspace_floats",
            "cv_interp_linear_cl", "cv_sizeof_groupnorm_params", "cv_relpos_append", "cv_sizeof_tblock_params", "cv_tblock_head",
            "cv_tblock_tail", "cv_sizeof_llm_step_desc", "cv_sizeof_llm_layer", "cv_llm_step_enqueue", "cv_llm_step_graph_create",

@@ -568,6 +568,43 @@ __global__ __launch_bounds__(256) void rope_append_kernel(const float* qkv, int 
   }
 }
 
+// =========================================================================================== fragment-tiled KV cache
+// The fused decode attention keeps each (sequence, kv head) cache as ctx_max/64 tiles of 8 KB in MFMA FRAGMENT ORDER, so a
+// wave's load of one fragment is 64 lanes x 16 contiguous bytes (8 full cache lines per instruction).  With the row-major
+// caches a fragment load touched 16 lines (64 B of each for K, 32 B for V^T: 384 line accesses per 64-key tile instead of
+// 128) and the one CU behind a (sequence, head) workgroup spent 5.4 of the kernel's 9 us getting 100 KB through its L1.
+//   K tile:  element ((kt*2 + f)*64 + lq + 16*lg)*8 + e  =  key 16*kt + lq,             d = 32*f + 8*lg + e
+//   V tile:  element ((dt*2 + s2)*64 + lq + 16*lg)*8 + e =  key 32*s2 + 16*(e>>2) + 4*lg + (e&3),   d = 16*dt + lq
+constexpr int KV_TILE = 64 * 64;   // elements per tile
+__device__ __forceinline__ int ktile_index(int key_rel, int d) {
+  return ((((key_rel >> 4) * 2 + (d >> 5)) * 64 + (key_rel & 15) + 16 * ((d >> 3) & 3)) << 3) + (d & 7);
+}
+__device__ __forceinline__ int vtile_index(int key_rel, int d) {
+  const int r = key_rel & 31;
+  return ((((d >> 4) * 2 + (key_rel >> 5)) * 64 + (d & 15) + 16 * ((r & 15) >> 2)) << 3) + (r & 3) + 4 * (r >> 4);
+}
+
+// row-major caches ([B][Hkv][ctx_max][64] keys x d, [B][Hkv][64][ctx_max] d x keys: what cv_rope_append writes and
+// cv_attention reads during prefill) -> fragment-tiled caches, tiles [0, ntiles)
+__global__ __launch_bounds__(256) void kv_retile_kernel(const uint16_t* k_rm, const uint16_t* vt_rm, uint16_t* k_t, uint16_t* vt_t, int ctx_max) {
+  const int t = blockIdx.x, bh = blockIdx.y;
+  const uint16_t* ks = k_rm + (int64_t)bh * ctx_max * 64 + (int64_t)t * 64 * 64;
+  const uint16_t* vs = vt_rm + (int64_t)bh * 64 * ctx_max + t * 64;
+  uint16_t* kd = k_t + ((int64_t)bh * (ctx_max >> 6) + t) * KV_TILE;
+  uint16_t* vd = vt_t + ((int64_t)bh * (ctx_max >> 6) + t) * KV_TILE;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = threadIdx.x + i * 256;          // 16-byte chunk of the tile: (fragment index, lane)
+    const int fr = c >> 6, lq = c & 15, lg = (c >> 4) & 3;
+    // K fragment fr = kt*2 + f: key 16*kt + lq, d = 32*f + 8*lg .. +7 (contiguous in the row-major row)
+    *(uint4*)(kd + c * 8) = *(const uint4*)(ks + ((fr >> 1) * 16 + lq) * 64 + 32 * (fr & 1) + 8 * lg);
+    // V fragment fr = dt*2 + s2: d = 16*dt + lq, keys 32*s2 + 4*lg .. +3 and + 16
+    const uint16_t* vr = vs + (int64_t)((fr >> 1) * 16 + lq) * ctx_max + 32 * (fr & 1) + 4 * lg;
+    const uint2 a = *(const uint2*)vr, b2 = *(const uint2*)(vr + 16);
+    *(uint4*)(vd + c * 8) = make_uint4(a.x, a.y, b2.x, b2.y);
+  }
+}
+
 // =========================================================================================== decode attention
 constexpr float NEG_BIG = -1e30f;
 constexpr int DA_WAVES = 8;
@@ -579,7 +616,7 @@ constexpr int DA_WAVES = 8;
 // and loaded a wave's second tile only after finishing its first: two more dependent HBM round trips, 8.5 us per call.)
 // FUSED is a template parameter, not `qkv != nullptr` at run time: a run-time branch around the qkv loads ends in PHIs
 // with the zero defaults, and hipcc then waits for those loads before it issues the K/V tile loads.
-template <int DT, bool FUSED>
+template <int DT, bool FUSED, int ABL = 0>   // ABL: timing-only ablations (CV_DA_ABL; results are wrong): 1 no MFMA/softmax, 2 no K/V loads
 __global__ __launch_bounds__(512) void decode_attn_kernel(const uint16_t* q, int ldq, uint16_t* kcache, uint16_t* vtcache,
                                                           const int32_t* ctx_len, int ctx_add, uint16_t* out, int ldo, int Hq, int Hkv,
                                                           int ctx_max, float scale, const float* qkv, int ldqkv, const float* inv_freq) {
@@ -590,15 +627,33 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(const uint16_t* q, int
   const int lq = lane & 15, lg = lane >> 4;
   const int hk = blockIdx.x, b = blockIdx.y;
   const int G = Hq / Hkv;  // query heads per kv head (<= 16)
+  // FUSED: fragment-tiled caches (above); otherwise row-major [ctx_max][64] / [64][ctx_max].  Same size per (b, hk) either way.
   uint16_t* Kb = kcache + ((int64_t)b * Hkv + hk) * ctx_max * 64;
   uint16_t* Vb = vtcache + ((int64_t)b * Hkv + hk) * 64 * ctx_max;
-  const int pos = ctx_len[b];
-  const int ctx = min(pos + ctx_add, ctx_max);
+  // `pos` through the vector memory path (a uniform plain load becomes s_load + lgkmcnt(0) at the top of the kernel, ahead of
+  // every other load): issued first, consumed after the qkv words and the first K/V tile are in flight (counted vmcnt).
+  const int pos_v = __builtin_amdgcn_raw_buffer_load_b32(
+      __builtin_amdgcn_make_buffer_rsrc((void*)ctx_len, 0, (int)gridDim.y * 4, 0x00020000), b * 4, 0, 0);
 
   // ---- loads of a tile pair: unconditional (rows beyond the cache end are clamped; invalid keys are masked later)
   uint4 kfA[4][2], kfB[4][2];
   uint2 vfA[4][2][2], vfB[4][2][2];
   auto load_tile = [&](uint4 (&kf)[4][2], uint2 (&vf)[4][2][2], int t) __attribute__((always_inline)) {
+    if constexpr (FUSED) {
+      const int tc = min(t, (ctx_max >> 6) - 1);
+      const uint4* kp = (const uint4*)(Kb + (int64_t)tc * KV_TILE) + lane;
+      const uint4* vp = (const uint4*)(Vb + (int64_t)tc * KV_TILE) + lane;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          kf[i][f] = kp[(i * 2 + f) * 64];
+          const uint4 v = vp[(i * 2 + f) * 64];
+          vf[i][f][0] = make_uint2(v.x, v.y);
+          vf[i][f][1] = make_uint2(v.z, v.w);
+        }
+      return;
+    }
     const int j0 = min(t << 6, ctx_max - 64);
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -629,9 +684,9 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(const uint16_t* q, int
   // loads (clamped head index) so the loads stay unconditional; lanes beyond the group zero their fragment afterwards.
   // Issue order = return order: the small qkv / rope-table words first, then the K/V tiles, so the rope arithmetic and the
   // LDS exchange run while the tiles are still in flight.
-  const int ntiles = (ctx + 63) >> 6;
   float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, b0 = a0, b1 = a0, c0 = a0, c1 = a0, s0 = a0, s1 = a0;
   float kx1 = 0.f, kx2 = 0.f, vx = 0.f, kcs = 0.f, ksn = 0.f;
+  const float* cs_row = nullptr;
   if constexpr (FUSED) {
     const float* row = qkv + (int64_t)b * ldqkv;
     const float* src = row + (hk * G + min(lq, G - 1)) * 64 + 8 * lg;
@@ -641,14 +696,31 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(const uint16_t* q, int
     const float* ks_ = row + Hq * 64 + hk * 64;
     kx1 = ks_[lane & 31]; kx2 = ks_[(lane & 31) + 32];
     vx = row[(Hq + Hkv) * 64 + hk * 64 + lane];
-    const float* cs_row = inv_freq + (int64_t)min(pos, ctx_max - 1) * 64;  // [pos][cos 32 | sin 32] table
+  }
+  // The first tile of every wave (keys < 512) is fetched unconditionally — its addresses do not depend on `pos`, so the loads
+  // leave with the qkv words instead of one L2 round trip later (tiles beyond the context are in bounds of the cache and are
+  // simply not used); the second tile (contexts beyond 512 keys) waits for `pos`.
+  if constexpr (ABL == 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      kfA[i][0] = kfA[i][1] = kfB[i][0] = kfB[i][1] = make_uint4(0, 0, 0, 0);
+      vfA[i][0][0] = vfA[i][0][1] = vfA[i][1][0] = vfA[i][1][1] = make_uint2(0, 0);
+      vfB[i][0][0] = vfB[i][0][1] = vfB[i][1][0] = vfB[i][1][1] = make_uint2(0, 0);
+    }
+  } else {
+    load_tile(kfA, vfA, min(wid, (ctx_max >> 6) - 1));
+  }
+  __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise hoists the wait for `pos` above half of these loads
+  const int pos = __builtin_amdgcn_readfirstlane(pos_v);
+  const int ctx = min(pos + ctx_add, ctx_max);
+  const int ntiles = (ctx + 63) >> 6;
+  if constexpr (FUSED) {   // the rope table row is the first load that needs `pos`
+    cs_row = inv_freq + (int64_t)min(pos, ctx_max - 1) * 64;  // [pos][cos 32 | sin 32] table
     c0 = *(const float4*)(cs_row + 8 * lg); c1 = *(const float4*)(cs_row + 8 * lg + 4);
     s0 = *(const float4*)(cs_row + 32 + 8 * lg); s1 = *(const float4*)(cs_row + 32 + 8 * lg + 4);
     kcs = cs_row[lane & 31]; ksn = cs_row[32 + (lane & 31)];
   }
-  // only tiles that hold valid keys are fetched (wave-uniform conditions around whole batches of loads)
-  if (wid < ntiles) load_tile(kfA, vfA, wid);
-  if (wid + DA_WAVES < ntiles) load_tile(kfB, vfB, wid + DA_WAVES);
+  if (ABL != 2 && wid + DA_WAVES < ntiles) load_tile(kfB, vfB, wid + DA_WAVES);
   if constexpr (FUSED) {
 #define ROPE_LO(x1, x2, c, s_) ((x1) * (c) - (x2) * (s_))
 #define ROPE_HI(x1, x2, c, s_) ((x2) * (c) + (x1) * (s_))
@@ -668,13 +740,14 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(const uint16_t* q, int
       s_newk[lane] = k1;
       s_newk[lane + 32] = k2;
       if (pos < ctx_max) {
-        Kb[(int64_t)pos * 64 + lane] = k1;
-        Kb[(int64_t)pos * 64 + lane + 32] = k2;
+        uint16_t* kt_ = Kb + (int64_t)(pos >> 6) * KV_TILE;
+        kt_[ktile_index(pos & 63, lane)] = k1;
+        kt_[ktile_index(pos & 63, lane + 32)] = k2;
       }
     } else if (wid == 1) {
       const uint16_t vv = Elem16<DT>::from_f32(vx);
       s_newv[lane] = vv;
-      if (pos < ctx_max) Vb[(int64_t)lane * ctx_max + pos] = vv;
+      if (pos < ctx_max) Vb[(int64_t)(pos >> 6) * KV_TILE + vtile_index(pos & 63, lane)] = vv;
     }
     __syncthreads();
   } else {
@@ -723,6 +796,16 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(const uint16_t* q, int
             vf[dt][s2][h] = make_uint2(x0, x1);
           }
       }
+    }
+    if constexpr (ABL == 1) {   // keep the loads alive, skip the arithmetic
+      uint32_t acc_ = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc_ ^= kf[i][0].x ^ kf[i][0].y ^ kf[i][0].z ^ kf[i][0].w ^ kf[i][1].x ^ kf[i][1].y ^ kf[i][1].z ^ kf[i][1].w;
+        acc_ ^= vf[i][0][0].x ^ vf[i][0][0].y ^ vf[i][0][1].x ^ vf[i][0][1].y ^ vf[i][1][0].x ^ vf[i][1][0].y ^ vf[i][1][1].x ^ vf[i][1][1].y;
+      }
+      oacc[0][0] += __uint_as_float(acc_ & 0x3F800000u);
+      return;
     }
     f32x4_t sacc[4];
 #pragma unroll
@@ -1300,6 +1383,19 @@ extern "C" int cv_rope_append(const float* qkv, int32_t ldqkv, const int32_t* po
   return CV_OK;
 }
 
+extern "C" int cv_kv_retile(const void* k_rm, const void* vt_rm, void* k_tiled, void* vt_tiled, int32_t B, int32_t Hkv,
+                            int32_t ctx_max, int32_t n_keys, void* stream) {
+  if (!k_rm || !vt_rm || !k_tiled || !vt_tiled || B <= 0 || Hkv <= 0 || ctx_max <= 0 || (ctx_max & 63) || n_keys < 0 || n_keys > ctx_max)
+    return CV_ERR_ARG;
+  if (((uintptr_t)k_rm | (uintptr_t)vt_rm | (uintptr_t)k_tiled | (uintptr_t)vt_tiled) & 15) return CV_ERR_ARG;
+  const int ntiles = (n_keys + 63) >> 6;
+  if (ntiles == 0) return CV_OK;
+  hipLaunchKernelGGL(kv_retile_kernel, dim3(ntiles, B * Hkv), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)k_rm,
+                     (const uint16_t*)vt_rm, (uint16_t*)k_tiled, (uint16_t*)vt_tiled, ctx_max);
+  CV_CHECK_LAUNCH();
+  return CV_OK;
+}
+
 extern "C" int cv_decode_attention(const void* q, int32_t ldq, const void* kcache, const void* vtcache, const int32_t* ctx_len,
                                    int32_t ctx_add, void* out, int32_t ldo, int32_t B, int32_t Hq, int32_t Hkv, int32_t ctx_max,
                                    float scale, int32_t dtype, const float* qkv, int32_t ldqkv, const float* inv_freq, void* stream) {
@@ -1308,7 +1404,16 @@ extern "C" int cv_decode_attention(const void* q, int32_t ldq, const void* kcach
   if (qkv && (!inv_freq || ldqkv < (Hq + 2 * Hkv) * 64)) return CV_ERR_ARG;
   if ((ldo & 3) || (ctx_max & 63)) return CV_ERR_ARG;
   dim3 grid(Hkv, B);
-  if (qkv) {
+  static const int abl = getenv("CV_DA_ABL") ? atoi(getenv("CV_DA_ABL")) : 0;
+  if (qkv && abl == 1) {
+    DISPATCH_16(dtype, hipLaunchKernelGGL((decode_attn_kernel<DT, true, 1>), grid, dim3(512), 0, (hipStream_t)stream, (const uint16_t*)q, ldq,
+                                          (uint16_t*)kcache, (uint16_t*)vtcache, ctx_len, ctx_add, (uint16_t*)out, ldo, Hq, Hkv,
+                                          ctx_max, scale, qkv, ldqkv, inv_freq));
+  } else if (qkv && abl == 2) {
+    DISPATCH_16(dtype, hipLaunchKernelGGL((decode_attn_kernel<DT, true, 2>), grid, dim3(512), 0, (hipStream_t)stream, (const uint16_t*)q, ldq,
+                                          (uint16_t*)kcache, (uint16_t*)vtcache, ctx_len, ctx_add, (uint16_t*)out, ldo, Hq, Hkv,
+                                          ctx_max, scale, qkv, ldqkv, inv_freq));
+  } else if (qkv) {
     DISPATCH_16(dtype, hipLaunchKernelGGL((decode_attn_kernel<DT, true>), grid, dim3(512), 0, (hipStream_t)stream, (const uint16_t*)q, ldq,
                                           (uint16_t*)kcache, (uint16_t*)vtcache, ctx_len, ctx_add, (uint16_t*)out, ldo, Hq, Hkv,
                                           ctx_max, scale, qkv, ldqkv, inv_freq));

@@ -134,8 +134,12 @@ class Qwen2LM:
                        max_len=z(16, dtype=torch.int32), out_tokens=z(16, self.max_out, dtype=torch.int32),
                        forced=torch.full((16, self.max_out), -1, device=dev, dtype=torch.int32),
                        uniforms=z(16, 101, 2), nonce=z(2, dtype=torch.int64))
+        # per-layer caches in the fragment-tiled layout of the fused decode attention (cv_kv_retile); the prefill writes one
+        # layer at a time into the row-major scratch pair (what cv_rope_append / cv_attention use) and re-tiles it
         self.kcache = [z(MB, cfg.num_kv_heads, self.ctx_max, 64, dtype=dt) for _ in range(cfg.num_layers)]
         self.vtcache = [z(MB, cfg.num_kv_heads, 64, self.ctx_max, dtype=dt) for _ in range(cfg.num_layers)]
+        self._k_rm = z(MB, cfg.num_kv_heads, self.ctx_max, 64, dtype=dt)
+        self._vt_rm = z(MB, cfg.num_kv_heads, 64, self.ctx_max, dtype=dt)
 
     # ------------------------------------------------------------------ decode step (graph-capturable)
     def _head_and_sample(self, B, use_forced, use_uniforms):
@@ -287,12 +291,13 @@ class Qwen2LM:
         for li, lay in enumerate(self.layers):
             ops.layernorm(x, lay["g_in"], None, cfg.rms_eps, rms=True, out_act=ws["xn"])
             ops.linear(ws["xn"], lay["wqkv"], bias=lay["bqkv"], out_f32=ws["qkv"])
-            ops.rope_append(ws["qkv"], st["pos"], rows, Lp, cfg.num_heads, cfg.num_kv_heads, self.inv_freq, ws["q"], self.kcache[li],
-                            self.vtcache[li], self.ctx_max)
-            ops.attention(ws["q"], self.kcache[li], self.vtcache[li], ws["ao"], B=B, H=cfg.num_heads, Hkv=cfg.num_kv_heads, Tq=Lp,
+            ops.rope_append(ws["qkv"], st["pos"], rows, Lp, cfg.num_heads, cfg.num_kv_heads, self.inv_freq, ws["q"], self._k_rm,
+                            self._vt_rm, self.ctx_max)
+            ops.attention(ws["q"], self._k_rm, self._vt_rm, ws["ao"], B=B, H=cfg.num_heads, Hkv=cfg.num_kv_heads, Tq=Lp,
                           Tk=Lp, scale=scale, q_bs=Lp * cfg.q_dim, ldq=cfg.q_dim, k_bs=cfg.num_kv_heads * self.ctx_max * 64,
                           k_hs=self.ctx_max * 64, ldk=64, vt_ld=self.ctx_max, o_bs=Lp * cfg.q_dim, ldo=cfg.q_dim, causal=True,
                           klen=klen)
+            ops.kv_retile(self._k_rm, self._vt_rm, self.kcache[li], self.vtcache[li], B, cfg.num_kv_heads, self.ctx_max, Lp)
             ops.linear(ws["ao"], lay["wo"], res=x, out_f32=x)
             ops.layernorm(x, lay["g_post"], None, cfg.rms_eps, rms=True, out_act=ws["xn"])
             ops.linear(ws["xn"], lay["wgu"], act=ops.ACT_SWIGLU, out_act=ws["h"])

@@ -490,6 +490,24 @@ def rope_append(qkv, pos_base, rows, rows_per_seq, Hq, Hkv, inv_freq, q_out, kca
                                    L.stream_ptr()), "cv_rope_append")
 
 
+def kv_retile(k_rm, vt_rm, k_tiled, vt_tiled, B, Hkv, ctx_max, n_keys):
+    """Row-major caches (rope_append's layout) -> the fragment-tiled caches the fused decode_attention reads and appends to."""
+    _req_cuda(k_rm, vt_rm, k_tiled, vt_tiled)
+    L.check(L.lib().cv_kv_retile(C.c_void_p(k_rm.data_ptr()), C.c_void_p(vt_rm.data_ptr()), C.c_void_p(k_tiled.data_ptr()),
+                                 C.c_void_p(vt_tiled.data_ptr()), B, Hkv, ctx_max, n_keys, L.stream_ptr()), "cv_kv_retile")
+
+
+def kv_tile_index(ctx_max, key, d, v=False):
+    """Element offset of (key, d) inside one (sequence, kv head) fragment-tiled cache (include/cosyvoice_amd.h, cv_kv_retile)."""
+    t, r = key >> 6, key & 63
+    if not v:
+        i = ((((r >> 4) * 2 + (d >> 5)) * 64 + (r & 15) + 16 * ((d >> 3) & 3)) << 3) + (d & 7)
+    else:
+        r32 = r & 31
+        i = ((((d >> 4) * 2 + (r >> 5)) * 64 + (d & 15) + 16 * ((r32 & 15) >> 2)) << 3) + (r32 & 3) + 4 * (r32 >> 4)
+    return t * 4096 + i
+
+
 def decode_attention(q, kcache, vtcache, ctx_len, ctx_add, out, B, Hq, Hkv, ctx_max, scale, qkv=None, inv_freq=None):
     """qkv (fp32 [B][ld]) + inv_freq: fused RoPE + KV append + attention (q then only carries the dtype)."""
     _req_cuda(q, kcache, vtcache, ctx_len, out, qkv, inv_freq)

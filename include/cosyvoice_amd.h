@@ -331,10 +331,20 @@ int cv_rope_append(const float* qkv, int32_t ldqkv, const int32_t* pos_base, int
  * q [B][ldq] 16-bit (row b), ctx_len[b] + ctx_add keys valid; out [B][ldo] 16-bit.
  * Fused form (qkv != NULL): q is ignored; the kernel first applies RoPE to row b of qkv fp32 [B][ldqkv]
  * (= [q | k | v], position ctx_len[b]; inv_freq is then the table rope[ctx_max][64] = [cos 32 | sin 32] per position),
- * appends K / V^T of its kv head to the caches, then attends (ctx_add = 1). */
+ * appends K / V^T of its kv head to the caches, then attends (ctx_add = 1).  In the fused form BOTH caches are
+ * FRAGMENT-TILED (cv_kv_retile below): per (sequence, kv head) ctx_max/64 tiles of 64 keys x 64 d in MFMA operand order, so every
+ * fragment load is 64 lanes x 16 contiguous bytes; the un-fused form reads the row-major caches cv_rope_append writes. */
 int cv_decode_attention(const void* q, int32_t ldq, const void* kcache, const void* vtcache, const int32_t* ctx_len,
                         int32_t ctx_add, void* out, int32_t ldo, int32_t B, int32_t Hq, int32_t Hkv, int32_t ctx_max,
                         float scale, int32_t dtype, const float* qkv, int32_t ldqkv, const float* inv_freq, void* stream);
+
+/* Row-major KV caches (cv_rope_append's layout, also what cv_attention reads during prefill) -> the fragment-tiled caches
+ * of the fused cv_decode_attention, keys [0, n_keys) rounded up to whole 64-key tiles.  Same buffer sizes
+ * ([B][Hkv][ctx_max*64] 16-bit elements each); ctx_max % 64 == 0.  Tile layout (element index inside a 4096-element tile):
+ *   K:   ((kt*2 + f)*64 + lq + 16*lg)*8 + e   = key 16*kt + lq,                         d = 32*f + 8*lg + e
+ *   V^T: ((dt*2 + s2)*64 + lq + 16*lg)*8 + e  = key 32*s2 + 16*(e >> 2) + 4*lg + (e & 3), d = 16*dt + lq */
+int cv_kv_retile(const void* k_rowmajor, const void* vt_rowmajor, void* k_tiled, void* vt_tiled, int32_t B, int32_t Hkv,
+                 int32_t ctx_max, int32_t n_keys, void* stream);
 
 /* Repetition-aware sampling on device (utils/common.py:109-146 ras_sampling/nucleus_sampling/random_sampling,
  * llm/llm.py:806-821 sampling_ids, :861-874 loop bookkeeping).  One workgroup per sequence. */

@@ -138,10 +138,22 @@ def test_rmsnorm_reduce_and_rope_decode_attention():
     out2 = torch.zeros_like(out)
     ang = torch.arange(ctx_max, dtype=torch.float32, device=dev)[:, None] * inv[None, :]
     tab = torch.cat([ang.cos(), ang.sin()], 1).contiguous()
-    ops.decode_attention(q, kc2, vc2, ctx0, 1, out2, B, Hq, Hkv, ctx_max, 0.125, qkv=qkv, inv_freq=tab)
+    # the fused form reads and appends to FRAGMENT-TILED caches (cv_kv_retile)
+    kt2, vt2 = torch.zeros_like(kc2), torch.zeros_like(vc2)
+    ops.kv_retile(kc2, vc2, kt2, vt2, B, Hkv, ctx_max, ctx_max)
+    ops.decode_attention(q, kt2, vt2, ctx0, 1, out2, B, Hq, Hkv, ctx_max, 0.125, qkv=qkv, inv_freq=tab)
     torch.cuda.synchronize()
-    assert (kc2[:B].float() - kc[:B].float()).abs().max().item() < 2e-2 and torch.equal(vc2[:B], vc[:B])
     assert (out2[:B].float() - out[:B].float()).abs().max().item() < 1e-2
+    # tiled caches after the append == re-tiled row-major caches that hold the three-kernel path's new K / V
+    kt_ref, vt_ref = torch.zeros_like(kc), torch.zeros_like(vc)
+    ops.kv_retile(kc, vc, kt_ref, vt_ref, B, Hkv, ctx_max, ctx_max)
+    torch.cuda.synchronize()
+    assert (kt2[:B].float() - kt_ref[:B].float()).abs().max().item() < 2e-2 and torch.equal(vt2[:B], vt_ref[:B])
+    # and the documented index map: element (key, d) of the row-major cache sits at kv_tile_index(key, d)
+    flat_k, flat_v = kt_ref.view(B, Hkv, -1), vt_ref.view(B, Hkv, -1)
+    for key, d in ((0, 0), (5, 63), (70, 17), (100, 40), (127, 31)):
+        assert torch.equal(flat_k[:, :, ops.kv_tile_index(ctx_max, key, d)], kc[:, :, key, d])
+        assert torch.equal(flat_v[:, :, ops.kv_tile_index(ctx_max, key, d, v=True)], vc[:, :, d, key])
     # fused RMSNorm prologue of the skinny GEMM == rmsnorm_reduce + plain skinny GEMM
     torch.manual_seed(5)
     W = (torch.randn(1152, H, device=dev) / H ** 0.5).to(dt)
