@@ -157,6 +157,34 @@ class LlmStepDesc(C.Structure):
     ]
 
 
+class FlowResnet(C.Structure):
+    _fields_ = [("w1_p", _vp), ("b1", _vp), ("g1", _vp), ("be1", _vp), ("w2_p", _vp), ("b2", _vp), ("g2", _vp), ("be2", _vp),
+                ("wr_p", _vp), ("br", _vp), ("cin", _i32), ("reserved", _i32)]
+
+
+class FlowTBlock(C.Structure):
+    _fields_ = [("g1", _vp), ("b1n", _vp), ("wqkv_p", _vp), ("wo_p", _vp), ("bo", _vp), ("g3", _vp), ("b3n", _vp),
+                ("w1_p", _vp), ("bf1", _vp), ("w2_p", _vp), ("bf2", _vp)]
+
+
+class FlowBlock(C.Structure):
+    _fields_ = [("res", FlowResnet), ("tb", C.POINTER(FlowTBlock)), ("n_tb", _i32), ("reserved", _i32)]
+
+
+class FlowSolverDesc(C.Structure):
+    _fields_ = [
+        ("dtype", _i32), ("B", _i32), ("T", _i32), ("Tp", _i32),
+        ("C", _i32), ("inner", _i32), ("ff", _i32), ("heads", _i32), ("in_ch", _i32), ("out_ch", _i32),
+        ("n_blocks", _i32), ("n_steps", _i32), ("cus", _i32), ("cfg_rate", _f32), ("eps", _f32),
+        ("blocks", C.POINTER(FlowBlock)),
+        ("down_w", _vp), ("down_b", _vp), ("up_w", _vp), ("up_b", _vp),
+        ("fin_w", _vp), ("fin_b", _vp), ("fin_g", _vp), ("fin_be", _vp), ("proj_w", _vp), ("proj_b", _vp),
+        ("tadd", _vp), ("dts", C.POINTER(C.c_float)),
+        ("x", _vp), ("mu", _vp), ("spks", _vp), ("cond", _vp), ("klen", _vp),
+        ("xin", _vp), ("h1", _vp), ("x32", _vp), ("qk", _vp), ("vt", _vp), ("ao", _vp), ("cat", _vp), ("d", _vp), ("v", _vp), ("c32a", _vp),
+    ]
+
+
 _lib = None
 
 
@@ -175,7 +203,8 @@ def lib():
             fn = getattr(_lib, f"cv_sizeof_{name}_params")
             if fn() != C.sizeof(st):
                 raise RuntimeError(f"ABI mismatch for cv_{name}_params: C {fn()} vs ctypes {C.sizeof(st)}")
-        for name, st in (("llm_step_desc", LlmStepDesc), ("llm_layer", LlmLayer)):
+        for name, st in (("llm_step_desc", LlmStepDesc), ("llm_layer", LlmLayer), ("flow_solver_desc", FlowSolverDesc),
+                         ("flow_block", FlowBlock), ("flow_tblock", FlowTBlock)):
             fn = getattr(_lib, f"cv_sizeof_{name}")
             if fn() != C.sizeof(st):
                 raise RuntimeError(f"ABI mismatch for cv_{name}: C {fn()} vs ctypes {C.sizeof(st)}")
@@ -192,7 +221,9 @@ EXPORTS = ["cv_version", "cv_arch", "cv_gemm", "cv_layernorm", "cv_attention",
            "cv_stft_magnitude", "cv_log_clamp_channels_first", "cv_groupnorm_cl", "cv_groupnorm_workspace_floats",
            "cv_interp_linear_cl", "cv_sizeof_groupnorm_params", "cv_relpos_append", "cv_sizeof_tblock_params", "cv_tblock_head",
            "cv_tblock_tail", "cv_sizeof_llm_step_desc", "cv_sizeof_llm_layer", "cv_llm_step_enqueue", "cv_llm_step_graph_create",
-           "cv_llm_step_graph_launch", "cv_llm_step_graph_destroy", "cv_sizeof_resblock_params", "cv_resblock_conv1", "cv_resblock_conv2"]
+           "cv_llm_step_graph_launch", "cv_llm_step_graph_destroy", "cv_sizeof_resblock_params", "cv_resblock_conv1", "cv_resblock_conv2",
+           "cv_sizeof_flow_solver_desc", "cv_sizeof_flow_block", "cv_sizeof_flow_tblock", "cv_flow_euler_enqueue",
+           "cv_flow_euler_graph_create", "cv_flow_euler_graph_launch", "cv_flow_euler_graph_destroy"]
 
 TORCH_DT = {torch.float32: CV_F32, torch.bfloat16: CV_BF16, torch.float16: CV_F16}
 DT_TORCH = {v: k for k, v in TORCH_DT.items()}

@@ -101,3 +101,143 @@ extern "C" int cv_llm_step_graph_create(const cv_llm_step_desc* d, void* capture
 }
 extern "C" int cv_llm_step_graph_launch(void* graph, void* stream) { return cv_graph_launch(graph, stream); }
 extern "C" int cv_llm_step_graph_destroy(void* graph) { return cv_graph_destroy(graph); }
+
+
+// ================================================================================================ flow-matching solver
+// cv_flow_euler_*: n_steps x [pack CFG rows -> estimator -> Euler update].  Behavioural spec: flow/flow_matching.py:72-124
+// (solve_euler, CFG batch of 2 per utterance) and flow/decoder.py:224-334 (ConditionalDecoder.forward); the launch sequence is the
+// one cosyvoice_amd/flow.py composes (ConditionalDecoder.forward_cl + CausalConditionalCFM.solve) and is tested equal to it.
+namespace {
+int conv_k3(const cv_flow_solver_desc& d, const void* a, int lda, const void* w, const float* bias, void* out_act, float* out_f32,
+            hipStream_t st) {
+  const int R = 2 * d.B, T = d.T, C = d.C;
+  cv_gemm_params p{};
+  p.dtype = d.dtype; p.M = T; p.N = C; p.K = 3 * C; p.batch = R; p.batch_inner = 0;
+  p.A = a; p.a_bs0 = (int64_t)T * lda; p.lda = lda; p.a_rows = T;
+  p.cin = C; p.a_row_stride = 1; p.tap_base = -2; p.tap_step = 1;
+  p.W = w; p.ldw = 3 * C; p.bias = bias; p.out_scale = 1.0f;
+  p.out_row_stride = 1;
+  if (out_act) { p.out_act = out_act; p.oa_bs0 = (int64_t)T * C; p.ldoa = C; }
+  if (out_f32) { p.out_f32 = out_f32; p.o32_bs0 = (int64_t)T * C; p.ldo32 = C; }
+  return cv_gemm(&p, st);
+}
+
+int enqueue_estimator(const cv_flow_solver_desc& d, const float* tadd_row, hipStream_t st) {
+  const int R = 2 * d.B, T = d.T, C = d.C, inner = d.inner;
+  const size_t esz = 2;
+  const void* a_in = d.xin;
+  int lda = d.in_ch, cin = d.in_ch;
+  for (int bi = 0; bi < d.n_blocks; ++bi) {
+    const cv_flow_block& blk = d.blocks[bi];
+    {   // causal resnet block: conv + LN + Mish + time term | conv + LN + Mish + 1x1 conv of the input
+      cv_resblock_params p{};
+      p.dtype = d.dtype; p.R = R; p.T = T; p.C = C; p.cin = cin;
+      p.a = a_in; p.lda = lda;
+      p.w1_p = blk.res.w1_p; p.b1 = blk.res.b1; p.g1 = blk.res.g1; p.be1 = blk.res.be1; p.tadd = tadd_row + (size_t)bi * C;
+      p.h1 = d.h1; p.ldh1 = C;
+      p.w2_p = blk.res.w2_p; p.b2 = blk.res.b2; p.g2 = blk.res.g2; p.be2 = blk.res.be2;
+      p.wr_p = blk.res.wr_p; p.br = blk.res.br;
+      p.out = d.x32; p.ldo = C; p.eps = d.eps; p.cus = d.cus;
+      if (int rc = cv_resblock_conv1(&p, st)) return rc;
+      if (int rc = cv_resblock_conv2(&p, st)) return rc;
+    }
+    for (int j = 0; j < blk.n_tb; ++j) {
+      const cv_flow_tblock& tb = blk.tb[j];
+      cv_tblock_params p{};
+      p.dtype = d.dtype; p.R = R; p.T = T; p.C = C; p.inner = inner; p.ff = d.ff;
+      p.x = d.x32; p.ldx = C; p.eps = d.eps; p.cus = d.cus;
+      p.g1 = tb.g1; p.b1n = tb.b1n; p.wqkv_p = tb.wqkv_p;
+      p.qk = d.qk; p.ldqk = 2 * inner; p.vt = d.vt; p.vt_ld = d.Tp;
+      if (int rc = cv_tblock_head(&p, st)) return rc;
+      cv_attn_params a{};
+      a.dtype = d.dtype; a.B = R; a.H = d.heads; a.Hkv = d.heads; a.Tq = T; a.Tk = T;
+      a.q = d.qk; a.q_bs = (int64_t)T * 2 * inner; a.ldq = 2 * inner;
+      a.k = (const char*)d.qk + (size_t)inner * esz; a.k_bs = (int64_t)T * 2 * inner; a.ldk = 2 * inner;
+      a.vt = d.vt; a.vt_ld = d.Tp;
+      a.out = d.ao; a.o_bs = (int64_t)T * inner; a.ldo = inner;
+      a.scale = 0.125f; a.klen = d.klen;
+      if (int rc = cv_attention(&a, st)) return rc;
+      p.ao = d.ao; p.ldao = inner; p.wo_p = tb.wo_p; p.bo = tb.bo; p.g3 = tb.g3; p.b3n = tb.b3n;
+      p.w1_p = tb.w1_p; p.bf1 = tb.bf1; p.w2_p = tb.w2_p; p.bf2 = tb.bf2;
+      if (j == blk.n_tb - 1) {   // 16-bit copy of the block output: skip tensor / next block's conv input (decoder.py:277,301)
+        if (bi == 0) { p.out_act = (char*)d.cat + (size_t)C * esz; p.ldoa = 2 * C; }
+        else if (bi == d.n_blocks - 2) { p.out_act = d.cat; p.ldoa = 2 * C; }
+        else { p.out_act = d.d; p.ldoa = C; }
+      }
+      if (int rc = cv_tblock_tail(&p, st)) return rc;
+    }
+    if (bi == 0) {   // downsample slot = CausalConv1d k3 on the skip tensor (decoder.py:278)
+      if (int rc = conv_k3(d, (const char*)d.cat + (size_t)C * esz, 2 * C, d.down_w, d.down_b, d.d, nullptr, st)) return rc;
+      a_in = d.d; lda = C; cin = C;
+    } else if (bi == d.n_blocks - 2) {
+      a_in = d.cat; lda = 2 * C; cin = 2 * C;
+    } else {
+      a_in = d.d; lda = C; cin = C;
+    }
+  }
+  // upsample slot, final block (conv + LN + Mish), final_proj (decoder.py:331-334)
+  if (int rc = conv_k3(d, d.d, C, d.up_w, d.up_b, d.h1, nullptr, st)) return rc;
+  if (int rc = conv_k3(d, d.h1, C, d.fin_w, d.fin_b, nullptr, d.c32a, st)) return rc;
+  const int rows = R * T;
+  {
+    cv_norm_params n{};
+    n.rows = rows; n.dim = C; n.rms = 0; n.eps = d.eps; n.x = d.c32a; n.ldx = C; n.gamma = d.fin_g; n.beta = d.fin_be;
+    n.act = CV_ACT_MISH; n.out_scale = 1.0f; n.out_dtype = d.dtype; n.out_act = d.h1; n.ldoa = C;
+    if (int rc = cv_layernorm(&n, st)) return rc;
+  }
+  cv_gemm_params g{};
+  g.dtype = d.dtype; g.M = rows; g.N = d.out_ch; g.K = C; g.batch = 1;
+  g.A = d.h1; g.lda = C; g.a_row_stride = 1; g.W = d.proj_w; g.ldw = C; g.bias = d.proj_b; g.out_scale = 1.0f;
+  g.out_f32 = d.v; g.ldo32 = d.out_ch; g.out_row_stride = 1;
+  return cv_gemm(&g, st);
+}
+
+int enqueue_solver(const cv_flow_solver_desc& d, hipStream_t st) {
+  for (int i = 0; i < d.n_steps; ++i) {
+    if (int rc = cv_est_pack(d.x, d.mu, d.spks, d.cond, d.xin, d.dtype, d.B, d.T, d.out_ch, st)) return rc;
+    if (int rc = enqueue_estimator(d, d.tadd + (size_t)i * d.n_blocks * d.C, st)) return rc;
+    if (int rc = cv_cfm_update(d.x, d.v, d.B, d.T, d.out_ch, d.dts[i], d.cfg_rate, st)) return rc;
+  }
+  return CV_OK;
+}
+
+int check_flow_desc(const cv_flow_solver_desc* d) {
+  if (!d || !d->blocks || !d->dts || d->n_blocks < 3 || d->n_steps <= 0) return CV_ERR_ARG;
+  if (d->dtype != CV_BF16 && d->dtype != CV_F16) return CV_ERR_UNSUPPORTED;
+  if (d->C != 256 || d->inner != 512 || d->ff != 1024 || d->heads != 8 || d->in_ch != 4 * d->out_ch) return CV_ERR_UNSUPPORTED;   // the fused kernels' shapes
+  if (d->B <= 0 || d->T <= 0 || d->Tp < d->T || (d->Tp & 7)) return CV_ERR_ARG;
+  if (!d->x || !d->mu || !d->spks || !d->cond || !d->tadd || !d->xin || !d->h1 || !d->x32 || !d->qk || !d->vt || !d->ao || !d->cat ||
+      !d->d || !d->v || !d->c32a || !d->down_w || !d->up_w || !d->fin_w || !d->fin_g || !d->fin_be || !d->proj_w) return CV_ERR_ARG;
+  for (int i = 0; i < d->n_blocks; ++i) {
+    const cv_flow_block& b = d->blocks[i];
+    if (b.n_tb <= 0 || !b.tb || !b.res.w1_p || !b.res.w2_p || !b.res.wr_p) return CV_ERR_ARG;
+    const int want = i == 0 ? d->in_ch : (i == d->n_blocks - 1 ? 2 * d->C : d->C);
+    if (b.res.cin != want) return CV_ERR_ARG;
+  }
+  return CV_OK;
+}
+}  // namespace
+
+extern "C" int cv_sizeof_flow_solver_desc(void) { return (int)sizeof(cv_flow_solver_desc); }
+extern "C" int cv_sizeof_flow_block(void) { return (int)sizeof(cv_flow_block); }
+extern "C" int cv_sizeof_flow_tblock(void) { return (int)sizeof(cv_flow_tblock); }
+
+extern "C" int cv_flow_euler_enqueue(const cv_flow_solver_desc* d, void* stream) {
+  if (int rc = check_flow_desc(d)) return rc;
+  return enqueue_solver(*d, (hipStream_t)stream);
+}
+
+extern "C" int cv_flow_euler_graph_create(const cv_flow_solver_desc* d, void* capture_stream, void** graph_out) {
+  if (!graph_out || !capture_stream) return CV_ERR_ARG;
+  if (int rc = check_flow_desc(d)) return rc;
+  if (int rc = cv_graph_begin(capture_stream)) return rc;
+  const int rc_body = enqueue_solver(*d, (hipStream_t)capture_stream);
+  void* g = nullptr;
+  const int rc_end = cv_graph_end(capture_stream, &g);
+  if (rc_body != CV_OK) { if (g) cv_graph_destroy(g); return rc_body; }
+  if (rc_end != CV_OK) return rc_end;
+  *graph_out = g;
+  return CV_OK;
+}
+extern "C" int cv_flow_euler_graph_launch(void* graph, void* stream) { return cv_graph_launch(graph, stream); }
+extern "C" int cv_flow_euler_graph_destroy(void* graph) { return cv_graph_destroy(graph); }

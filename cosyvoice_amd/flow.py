@@ -243,6 +243,12 @@ class ConditionalDecoder:
         return (os.environ.get("CV_FLOW_FUSED", "1") != "0" and self.dtype in (torch.float16, torch.bfloat16)
                 and cfg.est_channels == 256 and cfg.est_inner == 512 and cfg.est_head_dim == 64 and cfg.est_ff_mult == 4)
 
+    @property
+    def fused_all(self):
+        """Every block runs on the row-block kernels (what cv_flow_euler_* composes): fused widths and packed resnet weights."""
+        return (self.fused and os.environ.get("CV_FLOW_FUSED_RESNET", "1") != "0"
+                and all("w1_p" in blk["res"] and blk["res"]["wr"].shape[1] in (256, 320, 512) for blk in self.blocks))
+
     def _load_tblock(self, P, sd, name):
         wqk = torch.cat([sd[f"{name}.attn1.to_q.weight"].float(), sd[f"{name}.attn1.to_k.weight"].float()], 0)
         tb = dict(g1=P.f32(f"{name}.norm1.weight"), b1=P.f32(f"{name}.norm1.bias"),
@@ -467,6 +473,7 @@ class CausalConditionalCFM:
         self._noise_cl = self.rand_noise[0].t().contiguous().to(device)  # (15000, 80) channels-last
         self._graphs: Dict[tuple, tuple] = {}
         self.use_graph = False
+        self.use_stage_abi = os.environ.get("CV_FLOW_STAGE_ABI", "1") != "0"   # solver graph built by cv_flow_euler_graph_create
 
     def schedule(self, n_timesteps):
         """t values fed to the estimator and the dt of every Euler step, with the reference's fp32 accumulation order
@@ -506,20 +513,69 @@ class CausalConditionalCFM:
                 est.forward_cl(ws, R, tt[i], klen2)
                 ops.cfm_update(x, ws["v"], dts[i], self.inference_cfg_rate)
 
+        # stage-level ABI (cv_flow_euler_*): the library composes and captures the same launch sequence from a descriptor;
+        # `run` stays as the eager path and as the cross-check of the C composition (tests/test_flow_gpu.py)
+        stage_abi = self.use_stage_abi and est.fused_all
+
         if not self.use_graph:
             run()
             return x
         key = (B, T, n_timesteps, x.data_ptr(), mu.data_ptr(), spks.data_ptr(), cond.data_ptr(),
                0 if klen2 is None else klen2.data_ptr(), int(getattr(est, "cu_budget", 0) or 0), est.fused)
+        key = key + (stage_abi,)
         g = self._graphs.get(key)
         if g is None:
             run()  # warm every lazily-built table outside capture
             torch.cuda.synchronize()
-            g = ops.Graph().capture(run)
+            if stage_abi:
+                desc, keep = self.solver_desc(x, mu, spks, cond, klen2, ws, tt, dts)
+                g = ops.Graph.from_flow_solver(desc, keep)
+            else:
+                g = ops.Graph().capture(run)
             self._graphs[key] = g
             return x  # the eager warm-up already produced the result (x was advanced once)
         g.launch()
         return x
+
+    def solver_desc(self, x, mu, spks, cond, klen2, ws, tt, dts):
+        """cv_flow_solver_desc of this solve (include/cosyvoice_amd.h) + the host arrays it points to."""
+        from . import _lib as L
+        import ctypes as C
+        est, cfg = self.estimator, self.cfg
+        B, T, _ = x.shape
+        d = L.FlowSolverDesc()
+        d.dtype, d.B, d.T, d.Tp = L.TORCH_DT[est.dtype], B, T, ws["Tp"]
+        d.C, d.inner, d.ff, d.heads = cfg.est_channels, cfg.est_inner, cfg.est_channels * cfg.est_ff_mult, cfg.est_heads
+        d.in_ch, d.out_ch = cfg.est_in_channels, cfg.output_size
+        d.n_blocks, d.n_steps, d.cus = len(est.blocks), len(dts), int(getattr(est, "cu_budget", 0) or 0)
+        d.cfg_rate, d.eps = self.inference_cfg_rate, 1e-5
+        blocks = (L.FlowBlock * len(est.blocks))()
+        keep = [blocks]
+        for bi, blk in enumerate(est.blocks):
+            rs, r = blk["res"], blocks[bi].res
+            for f, k in (("w1_p", "w1_p"), ("b1", "b1"), ("g1", "g1"), ("be1", "be1"), ("w2_p", "w2_p"), ("b2", "b2"), ("g2", "g2"),
+                         ("be2", "be2"), ("wr_p", "wr_p"), ("br", "br")):
+                setattr(r, f, rs[k].data_ptr())
+            r.cin = rs["wr"].shape[1]
+            tbs = (L.FlowTBlock * len(blk["tb"]))()
+            keep.append(tbs)
+            for j, tb in enumerate(blk["tb"]):
+                for f, k in (("g1", "g1"), ("b1n", "b1"), ("wqkv_p", "wqkv_p"), ("wo_p", "wo_p"), ("bo", "bo"), ("g3", "g3"), ("b3n", "b3"),
+                             ("w1_p", "wf1_p"), ("bf1", "bf1"), ("w2_p", "wf2_p"), ("bf2", "bf2")):
+                    setattr(tbs[j], f, tb[k].data_ptr())
+            blocks[bi].tb, blocks[bi].n_tb = tbs, len(blk["tb"])
+        d.blocks = blocks
+        for f in ("down_w", "down_b", "up_w", "up_b", "fin_w", "fin_b", "fin_g", "fin_be", "proj_w", "proj_b"):
+            setattr(d, f, getattr(est, f).data_ptr())
+        tt_c = tt.contiguous()
+        dts_c = (C.c_float * len(dts))(*dts)
+        keep += [tt_c, dts_c]
+        d.tadd, d.dts = tt_c.data_ptr(), dts_c
+        d.x, d.mu, d.spks, d.cond = x.data_ptr(), mu.data_ptr(), spks.data_ptr(), cond.data_ptr()
+        d.klen = None if klen2 is None else klen2.data_ptr()
+        for f in ("xin", "h1", "x32", "qk", "vt", "ao", "cat", "d", "v", "c32a"):
+            setattr(d, f, ws[f].data_ptr())
+        return d, keep
 
     @torch.no_grad()
     def forward(self, mu, mask, n_timesteps, temperature=1.0, spks=None, cond=None):

@@ -343,6 +343,19 @@ class Graph:
         self._desc = desc   # keeps the host-side layer array alive
         return self
 
+    @classmethod
+    def from_flow_solver(cls, desc, keep=()):
+        """Graph of a whole CFM Euler solve (n_steps x [pack -> estimator -> update]), composed and captured by the library
+        (cv_flow_euler_graph_create).  ``keep``: host-side arrays the descriptor points to."""
+        self = cls()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            L.check(L.lib().cv_flow_euler_graph_create(C.byref(desc), L.stream_ptr(), C.byref(self.handle)), "cv_flow_euler_graph_create")
+        torch.cuda.current_stream().wait_stream(side)
+        self._desc, self._keep = desc, keep
+        return self
+
     def launch(self):
         """Replay on torch's current stream: as a hipGraphExec, or — when that stream is CU-masked (``masked_stream``) —
         launch by launch, because hipGraph replays ignore a stream's CU mask."""

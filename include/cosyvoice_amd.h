@@ -390,7 +390,7 @@ typedef struct cv_llm_layer {
   const void* p_gu;                       /* cv_pack_skinny([gate; up] * post_attention_layernorm.weight, interleave = 1) */
   const void* p_down;                     /* cv_pack_skinny(down_proj) (hidden rows, K = intermediate) */
   const float* g_in;                      /* input_layernorm.weight [hidden] */
-  void* kcache; void* vtcache;            /* [B_max][Hkv][ctx_max][64], [B_max][Hkv][64][ctx_max] */
+  void* kcache; void* vtcache;            /* [B_max][Hkv][ctx_max*64] each, FRAGMENT-TILED (cv_kv_retile) */
 } cv_llm_layer;
 typedef struct cv_llm_step_desc {
   int32_t dtype, B, num_layers, hidden, num_heads, num_kv_heads, inter, ctx_max, down_ksplit; float rms_eps;
@@ -412,6 +412,51 @@ int cv_llm_step_enqueue(const cv_llm_step_desc* d, void* stream);
 int cv_llm_step_graph_create(const cv_llm_step_desc* d, void* capture_stream, void** graph_out);
 int cv_llm_step_graph_launch(void* graph, void* stream);
 int cv_llm_step_graph_destroy(void* graph);
+
+/* cv_flow_euler_*: the whole flow-matching solve behind one call — n_steps x [cv_est_pack -> CFM estimator ->
+ * cv_cfm_update] for B utterances (2B CFG rows), T frames.  Replaces ConditionalCFM.solve_euler
+ * (flow/flow_matching.py:72-124) and ConditionalDecoder.forward (flow/decoder.py:224-334: down block, 12 mid blocks, up block,
+ * final block, final_proj), each block = causal resnet (cv_resblock_conv1/2) + n_tb transformer blocks
+ * (cv_tblock_head -> cv_attention -> cv_tblock_tail); the down / up slots and the final block are causal k3 convs
+ * (cv_gemm with taps) + LayerNorm + Mish (cv_layernorm) + final_proj (cv_gemm).
+ * `blocks`, every `tb` array and `dts` are HOST arrays read at enqueue / capture time only; all other pointers are caller-owned
+ * device buffers.  Weights: *_p = cv_pack_skinny fragment order (resnet conv K zero-padded to a multiple of 128 per tap group as
+ * cv_resblock_params describes); down_w / up_w / fin_w [C][3*C] and proj_w [out_ch][C] row-major 16-bit (k = tap*C + ci).
+ * tadd[step][block*C + c] = the block's time-MLP output for that step (fp32, depends only on t: computed once per schedule). */
+typedef struct cv_flow_resnet {
+  const void* w1_p; const float* b1; const float* g1; const float* be1;
+  const void* w2_p; const float* b2; const float* g2; const float* be2;
+  const void* wr_p; const float* br;
+  int32_t cin; int32_t reserved;
+} cv_flow_resnet;
+typedef struct cv_flow_tblock {
+  const float* g1; const float* b1n; const void* wqkv_p;
+  const void* wo_p; const float* bo; const float* g3; const float* b3n;
+  const void* w1_p; const float* bf1; const void* w2_p; const float* bf2;
+} cv_flow_tblock;
+typedef struct cv_flow_block { cv_flow_resnet res; const cv_flow_tblock* tb; int32_t n_tb; int32_t reserved; } cv_flow_block;
+typedef struct cv_flow_solver_desc {
+  int32_t dtype, B, T, Tp;                 /* Tp = V^T row pitch (T rounded up to 8) */
+  int32_t C, inner, ff, heads, in_ch, out_ch;   /* 256, 512, 1024, 8, 320, 80 */
+  int32_t n_blocks, n_steps, cus; float cfg_rate, eps;
+  const cv_flow_block* blocks;             /* host [n_blocks]: down, mid..., up */
+  const void* down_w; const float* down_b; const void* up_w; const float* up_b;
+  const void* fin_w; const float* fin_b; const float* fin_g; const float* fin_be; const void* proj_w; const float* proj_b;
+  const float* tadd;                       /* device [n_steps][n_blocks * C] */
+  const float* dts;                        /* host [n_steps] */
+  float* x; const float* mu; const float* spks; const float* cond;   /* [B][T][out_ch] state (in place), mu, cond; spks [B][out_ch] */
+  const int32_t* klen;                     /* [2B] valid frames per CFG row, or NULL */
+  /* workspace for R = 2B rows: xin [R][T][in_ch], h1 [R][T][C], qk [R][T][2*inner], vt [R][heads][64][Tp] (zero-initialised),
+   * ao [R][T][inner], cat [R][T][2C], d [R][T][C] (all `dtype`); x32, c32a [R][T][C] fp32; v [R][T][out_ch] fp32 */
+  void* xin; void* h1; float* x32; void* qk; void* vt; void* ao; void* cat; void* d; float* v; float* c32a;
+} cv_flow_solver_desc;
+int cv_sizeof_flow_solver_desc(void);
+int cv_sizeof_flow_block(void);
+int cv_sizeof_flow_tblock(void);
+int cv_flow_euler_enqueue(const cv_flow_solver_desc* d, void* stream);
+int cv_flow_euler_graph_create(const cv_flow_solver_desc* d, void* capture_stream, void** graph_out);
+int cv_flow_euler_graph_launch(void* graph, void* stream);
+int cv_flow_euler_graph_destroy(void* graph);
 
 int cv_sizeof_gemm_params(void);
 int cv_sizeof_norm_params(void);

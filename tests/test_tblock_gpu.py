@@ -201,3 +201,35 @@ def test_resblock_vs_torch(dt, tol, cin, T):
         print(f"resblock[{dt}, cin={cin}, T={T}, MT={mt}]: h1 Linf {e1:.3e}  out Linf {e2:.3e} (values ~ {ref.abs().mean().item():.2f})")
         assert e1 < tol and e2 < tol
     os.environ.pop("CV_TBLOCK_MT", None)
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_stage_abi_solver_equals_python_composed_solver(ragged, monkeypatch):
+    """cv_flow_euler_graph_create (the library composes n_steps x [pack -> estimator -> Euler update] from a descriptor and captures
+    it) vs the graph captured from cosyvoice_amd/flow.py's own launch sequence: same kernels, same order -> bit-identical state."""
+    from cosyvoice_amd.config import FlowConfig
+    from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
+    from cosyvoice_amd.weights import flow_state_dict
+    cfg = FlowConfig.tiny()
+    flow = CausalMaskedDiffWithXvec(cfg, dtype=torch.float16).load_state_dict(flow_state_dict(cfg))
+    cfm = flow.decoder
+    assert cfm.estimator.fused_all and cfm.use_stage_abi
+    cfm.use_graph = True
+    B, T = 2, 150
+    g = torch.Generator().manual_seed(1)
+    mu = torch.randn(B, T, 80, generator=g).cuda()
+    cond = torch.randn(B, T, 80, generator=g).cuda()
+    spks = torch.randn(B, 80, generator=g).cuda()
+    klen = torch.tensor([T, T - 37], dtype=torch.int32, device="cuda") if ragged else None
+    x0 = torch.randn(B, T, 80, generator=g).cuda()
+    res = {}
+    for abi in (True, False):
+        cfm.use_stage_abi = abi
+        x = x0.clone()
+        cfm.solve(x, mu, spks, cond, 4, klen=klen)          # first call: eager warm-up + graph build
+        x.copy_(x0)
+        cfm.solve(x, mu, spks, cond, 4, klen=klen)          # second call: graph replay
+        torch.cuda.synchronize()
+        res[abi] = x.clone()
+    assert len(cfm._graphs) == 2
+    assert torch.isfinite(res[True]).all() and torch.equal(res[True], res[False])

@@ -11,10 +11,10 @@ from cosyvoice_amd.llm import Qwen2LM
 from cosyvoice_amd.weights import llm_state_dict
 
 lc, fc = LlmConfig.full(), FlowConfig.full()
-llm = Qwen2LM(lc, dtype=torch.bfloat16, max_batch=8, ctx_max=704, max_out=258)
+llm = Qwen2LM(lc, dtype=torch.bfloat16, max_batch=int(__import__("os").environ.get("LKB_B", "8")), ctx_max=704, max_out=258)
 llm.load_state_dict(llm_state_dict(lc))
-texts, forced, ptext, pspeech, pfeat, emb = B.make_inputs(lc, fc, 100)
-dev = 'cuda'; Bn = 8
+texts, forced, ptext, pspeech, pfeat, emb = B.make_inputs(lc, fc, 100, n_utts=int(__import__("os").environ.get("LKB_B", "8")))
+dev = "cuda"; Bn = int(__import__("os").environ.get("LKB_B", "8"))
 texts_d = [t.to(dev) for t in texts]; pt, ps = ptext.to(dev), pspeech.to(dev)
 llm.generate_batch(texts_d, [pt]*Bn, [ps]*Bn, forced=forced, max_steps=int(__import__('os').environ.get('LKB_STEPS', '120')))   # caches filled to ctx ~400, state valid
 torch.cuda.synchronize()
