@@ -185,6 +185,37 @@ class FlowSolverDesc(C.Structure):
     ]
 
 
+class HiftConv(C.Structure):
+    _fields_ = [("w", _vp), ("b", _vp), ("k", _i32), ("cin", _i32), ("cout", _i32), ("dilation", _i32), ("pad_left", _i32), ("stride", _i32)]
+
+
+class HiftResunit(C.Structure):
+    _fields_ = [("c1", HiftConv), ("c2", HiftConv), ("a1", _vp), ("a2", _vp)]
+
+
+class HiftResblock(C.Structure):
+    _fields_ = [("units", C.POINTER(HiftResunit)), ("n_units", _i32), ("reserved", _i32)]
+
+
+class HiftPhase(C.Structure):
+    _fields_ = [("w", _vp), ("ntaps", _i32), ("tap_base", _i32)]
+
+
+class HiftStage(C.Structure):
+    _fields_ = [("phases", C.POINTER(HiftPhase)), ("up_b", _vp), ("u", _i32), ("up_cin", _i32),
+                ("source_down", HiftConv), ("source_rb", HiftResblock), ("rbs", C.POINTER(HiftResblock)),
+                ("t_out", _i32), ("c", _i32),
+                ("x32", _vp), ("xa", C.POINTER(_vp)), ("r0", _vp), ("r1", _vp), ("ta", _vp), ("ra", _vp), ("acc0", _vp), ("acc1", _vp),
+                ("si0", _vp), ("si1", _vp), ("out", _vp)]
+
+
+class HiftDecodeDesc(C.Structure):
+    _fields_ = [("dtype", _i32), ("gemm_dtype", _i32), ("B", _i32), ("T", _i32), ("S", _i32), ("n_stages", _i32), ("n_kernels", _i32),
+                ("stft_ld", _i32), ("hop", _i32), ("lrelu_slope", _f32), ("audio_limit", _f32),
+                ("conv_pre", HiftConv), ("conv_post", HiftConv), ("stages", C.POINTER(HiftStage)),
+                ("mel_cl", _vp), ("s", _vp), ("stft", _vp), ("a_pre", _vp), ("post", _vp), ("wav", _vp)]
+
+
 _lib = None
 
 
@@ -204,7 +235,8 @@ def lib():
             if fn() != C.sizeof(st):
                 raise RuntimeError(f"ABI mismatch for cv_{name}_params: C {fn()} vs ctypes {C.sizeof(st)}")
         for name, st in (("llm_step_desc", LlmStepDesc), ("llm_layer", LlmLayer), ("flow_solver_desc", FlowSolverDesc),
-                         ("flow_block", FlowBlock), ("flow_tblock", FlowTBlock)):
+                         ("flow_block", FlowBlock), ("flow_tblock", FlowTBlock), ("hift_decode_desc", HiftDecodeDesc),
+                         ("hift_stage", HiftStage), ("hift_resunit", HiftResunit)):
             fn = getattr(_lib, f"cv_sizeof_{name}")
             if fn() != C.sizeof(st):
                 raise RuntimeError(f"ABI mismatch for cv_{name}: C {fn()} vs ctypes {C.sizeof(st)}")
@@ -223,7 +255,9 @@ EXPORTS = ["cv_version", "cv_arch", "cv_gemm", "cv_layernorm", "cv_attention",
            "cv_tblock_tail", "cv_sizeof_llm_step_desc", "cv_sizeof_llm_layer", "cv_llm_step_enqueue", "cv_llm_step_graph_create",
            "cv_llm_step_graph_launch", "cv_llm_step_graph_destroy", "cv_sizeof_resblock_params", "cv_resblock_conv1", "cv_resblock_conv2",
            "cv_sizeof_flow_solver_desc", "cv_sizeof_flow_block", "cv_sizeof_flow_tblock", "cv_flow_euler_enqueue",
-           "cv_flow_euler_graph_create", "cv_flow_euler_graph_launch", "cv_flow_euler_graph_destroy"]
+           "cv_flow_euler_graph_create", "cv_flow_euler_graph_launch", "cv_flow_euler_graph_destroy",
+           "cv_sizeof_hift_decode_desc", "cv_sizeof_hift_stage", "cv_sizeof_hift_resunit", "cv_hift_decode_enqueue",
+           "cv_hift_decode_graph_create"]
 
 TORCH_DT = {torch.float32: CV_F32, torch.bfloat16: CV_BF16, torch.float16: CV_F16}
 DT_TORCH = {v: k for k, v in TORCH_DT.items()}

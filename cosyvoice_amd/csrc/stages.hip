@@ -241,3 +241,149 @@ extern "C" int cv_flow_euler_graph_create(const cv_flow_solver_desc* d, void* ca
 }
 extern "C" int cv_flow_euler_graph_launch(void* graph, void* stream) { return cv_graph_launch(graph, stream); }
 extern "C" int cv_flow_euler_graph_destroy(void* graph) { return cv_graph_destroy(graph); }
+
+
+// ================================================================================================ HiFT decode
+// cv_hift_decode_*: HiFTGenerator.decode, hifigan/generator.py:349-381 (ResBlock :91-98, SourceModule STFT :333-347).  The launch
+// sequence is the one cosyvoice_amd/hift.py composes (_decode_cl_impl / _resblock) and is tested equal to it.
+namespace {
+struct Epi {   // epilogue of one conv launch
+  const float* res = nullptr; const float* res2 = nullptr; float out_scale = 1.0f;
+  int act = CV_ACT_NONE; const float* act_param = nullptr; float act_slope = 0.0f;
+  float* out_f32 = nullptr; int ldo32 = 0; void* out_act = nullptr;
+};
+
+int hconv(const cv_hift_decode_desc& d, const cv_hift_conv& c, const void* x, int T_in, int T_out, const Epi& e, hipStream_t st) {
+  cv_gemm_params p{};
+  p.dtype = d.gemm_dtype; p.M = T_out; p.N = c.cout; p.K = c.k * c.cin; p.batch = d.B;
+  p.A = x; p.a_bs0 = (int64_t)T_in * c.cin; p.lda = c.cin; p.a_rows = T_in;
+  p.cin = c.cin; p.a_row_stride = c.stride; p.tap_base = -c.pad_left; p.tap_step = c.dilation;
+  p.W = c.w; p.ldw = c.k * c.cin; p.bias = c.b;
+  if (e.res) { p.res = e.res; p.res_bs0 = (int64_t)T_out * c.cout; p.ldres = c.cout; }
+  if (e.res2) { p.res2 = e.res2; p.ldres2 = c.cout; }
+  p.out_scale = e.out_scale; p.act = e.act; p.act_param = e.act_param; p.act_slope = e.act_slope;
+  if (e.out_f32) { const int ld = e.ldo32 ? e.ldo32 : c.cout; p.out_f32 = e.out_f32; p.o32_bs0 = (int64_t)T_out * ld; p.ldo32 = ld; }
+  if (e.out_act) { p.out_act = e.out_act; p.oa_bs0 = (int64_t)T_out * c.cout; p.ldoa = c.cout; }
+  p.out_row_stride = 1;
+  return cv_gemm(&p, st);
+}
+
+// ResBlock (generator.py:91-98): x -> x + c2(snake(c1(snake(x)))) per unit; xa = snake_{a1[0]}(x32) already computed
+int hresblock(const cv_hift_decode_desc& d, const cv_hift_resblock& rb, const cv_hift_stage& sg, const float* x32, const void* xa,
+              const Epi& fin, hipStream_t st) {
+  const float* cur32 = x32;
+  const void* cur_a = xa;
+  const int t = sg.t_out;
+  for (int j = 0; j < rb.n_units; ++j) {
+    const cv_hift_resunit& u = rb.units[j];
+    Epi e1; e1.act = CV_ACT_SNAKE; e1.act_param = u.a2; e1.out_act = sg.ta;
+    if (int rc = hconv(d, u.c1, cur_a, t, t, e1, st)) return rc;
+    if (j < rb.n_units - 1) {
+      float* nxt = (j & 1) ? sg.r1 : sg.r0;
+      Epi e2; e2.res = cur32; e2.out_f32 = nxt; e2.act = CV_ACT_SNAKE; e2.act_param = rb.units[j + 1].a1; e2.out_act = sg.ra;
+      if (int rc = hconv(d, u.c2, sg.ta, t, t, e2, st)) return rc;
+      cur32 = nxt; cur_a = sg.ra;
+    } else {
+      Epi e2 = fin; e2.res = cur32;
+      if (int rc = hconv(d, u.c2, sg.ta, t, t, e2, st)) return rc;
+    }
+  }
+  return CV_OK;
+}
+
+int enqueue_hift_decode(const cv_hift_decode_desc& d, hipStream_t st) {
+  const int B = d.B, F = d.S / d.hop + 1;
+  if (int rc = cv_stft16(d.s, d.stft, d.dtype, B, d.S, d.stft_ld, st)) return rc;
+  {
+    Epi e; e.act = CV_ACT_LEAKY; e.act_slope = d.lrelu_slope; e.out_act = d.a_pre;
+    if (int rc = hconv(d, d.conv_pre, d.mel_cl, d.T, d.T, e, st)) return rc;
+  }
+  const void* cur_a = d.a_pre;
+  int t_in = d.T;
+  for (int i = 0; i < d.n_stages; ++i) {
+    const cv_hift_stage& sg = d.stages[i];
+    const int t_out = sg.t_out, c = sg.c;
+    const bool last = i == d.n_stages - 1;
+    {   // source branch (generator.py:361-363): strided conv of the source STFT, then its ResBlock -> si1
+      Epi e; e.out_f32 = sg.si0; e.act = CV_ACT_SNAKE; e.act_param = sg.source_rb.units[0].a1; e.out_act = sg.xa[0];
+      if (int rc = hconv(d, sg.source_down, d.stft, F, t_out, e, st)) return rc;
+      Epi fin; fin.out_f32 = sg.si1;
+      if (int rc = hresblock(d, sg.source_rb, sg, sg.si0, sg.xa[0], fin, st)) return rc;
+    }
+    // ups[i] as u phase GEMMs (+ reflect pad on the last stage) + source fusion: x = ups(x) + si (generator.py:355-364)
+    auto phase = [&](const cv_hift_phase& ph, int M, int row_off) {
+      cv_gemm_params p{};
+      p.dtype = d.gemm_dtype; p.M = M; p.N = c; p.K = ph.ntaps * sg.up_cin; p.batch = B;
+      p.A = cur_a; p.a_bs0 = (int64_t)t_in * sg.up_cin; p.lda = sg.up_cin; p.a_rows = t_in;
+      p.cin = sg.up_cin; p.a_row_stride = 1; p.tap_base = ph.tap_base; p.tap_step = -1;
+      p.W = ph.w; p.ldw = ph.ntaps * sg.up_cin; p.bias = sg.up_b;
+      p.res = sg.si1; p.res_bs0 = (int64_t)t_out * c; p.ldres = c; p.out_scale = 1.0f;
+      p.out_f32 = sg.x32; p.o32_bs0 = (int64_t)t_out * c; p.ldo32 = c;
+      p.out_row_stride = sg.u; p.out_row_off = row_off; p.out_rows = t_out;
+      return cv_gemm(&p, st);
+    };
+    const int off = last ? 1 : 0;
+    for (int r = 0; r < sg.u; ++r)
+      if (int rc = phase(sg.phases[r], t_in, r + off)) return rc;
+    if (last)   // ReflectionPad1d((1, 0)): padded[0] = ups_out[1] = phase r = 1, q = 0
+      if (int rc = phase(sg.phases[1], 1, 0)) return rc;
+    // parallel ResBlocks, mean over kernels (generator.py:366-372), then leaky-relu (:353 / :374)
+    {
+      const float* alphas[8]; void* outs[8];
+      for (int j = 0; j < d.n_kernels; ++j) { alphas[j] = sg.rbs[j].units[0].a1; outs[j] = sg.xa[j]; }
+      if (int rc = cv_snake_multi(sg.x32, B * t_out, c, c, d.n_kernels, alphas, outs, c, d.dtype, st)) return rc;
+    }
+    const float slope = last ? 0.01f : d.lrelu_slope;   // F.leaky_relu default after the loop (generator.py:374)
+    for (int j = 0; j < d.n_kernels; ++j) {
+      Epi fin;
+      if (j < d.n_kernels - 1) fin.out_f32 = (j & 1) ? sg.acc1 : sg.acc0;
+      else { fin.out_scale = 1.0f / d.n_kernels; fin.act = CV_ACT_LEAKY; fin.act_slope = slope; fin.out_act = sg.out; }
+      if (j > 0) fin.res2 = ((j - 1) & 1) ? sg.acc1 : sg.acc0;
+      if (int rc = hresblock(d, sg.rbs[j], sg, sg.x32, sg.xa[j], fin, st)) return rc;
+    }
+    cur_a = sg.out;
+    t_in = t_out;
+  }
+  {
+    Epi e; e.out_f32 = d.post; e.ldo32 = d.stft_ld;
+    if (int rc = hconv(d, d.conv_post, cur_a, t_in, t_in, e, st)) return rc;
+  }
+  return cv_istft16(d.post, d.wav, B, t_in, d.stft_ld, d.audio_limit, st);
+}
+
+int check_hift_desc(const cv_hift_decode_desc* d) {
+  if (!d || !d->stages || d->n_stages <= 0 || d->n_kernels <= 0 || d->n_kernels > 4) return CV_ERR_ARG;
+  if (d->B <= 0 || d->T <= 0 || d->S <= 0 || d->hop != 4 || d->stft_ld < 18) return CV_ERR_ARG;
+  if (!d->mel_cl || !d->s || !d->stft || !d->a_pre || !d->post || !d->wav || !d->conv_pre.w || !d->conv_post.w) return CV_ERR_ARG;
+  for (int i = 0; i < d->n_stages; ++i) {
+    const cv_hift_stage& g = d->stages[i];
+    if (!g.phases || g.u < 2 || !g.rbs || !g.xa || !g.x32 || !g.r0 || !g.r1 || !g.ta || !g.ra || !g.acc0 || !g.acc1 || !g.si0 || !g.si1 ||
+        !g.out || !g.source_rb.units || g.source_rb.n_units <= 0 || g.t_out <= 0 || g.c <= 0) return CV_ERR_ARG;
+    for (int j = 0; j < d->n_kernels; ++j)
+      if (!g.rbs[j].units || g.rbs[j].n_units <= 0 || !g.xa[j]) return CV_ERR_ARG;
+  }
+  return CV_OK;
+}
+}  // namespace
+
+extern "C" int cv_sizeof_hift_decode_desc(void) { return (int)sizeof(cv_hift_decode_desc); }
+extern "C" int cv_sizeof_hift_stage(void) { return (int)sizeof(cv_hift_stage); }
+extern "C" int cv_sizeof_hift_resunit(void) { return (int)sizeof(cv_hift_resunit); }
+
+extern "C" int cv_hift_decode_enqueue(const cv_hift_decode_desc* d, void* stream) {
+  if (int rc = check_hift_desc(d)) return rc;
+  return enqueue_hift_decode(*d, (hipStream_t)stream);
+}
+
+extern "C" int cv_hift_decode_graph_create(const cv_hift_decode_desc* d, void* capture_stream, void** graph_out) {
+  if (!graph_out || !capture_stream) return CV_ERR_ARG;
+  if (int rc = check_hift_desc(d)) return rc;
+  if (int rc = cv_graph_begin(capture_stream)) return rc;
+  const int rc_body = enqueue_hift_decode(*d, (hipStream_t)capture_stream);
+  void* g = nullptr;
+  const int rc_end = cv_graph_end(capture_stream, &g);
+  if (rc_body != CV_OK) { if (g) cv_graph_destroy(g); return rc_body; }
+  if (rc_end != CV_OK) return rc_end;
+  *graph_out = g;
+  return CV_OK;
+}

@@ -8,6 +8,7 @@ channels-last activations, every Conv1d / ConvTranspose1d as an implicit-GEMM MF
 the Snake / leaky-relu / residual / 1/3-mean fused into the epilogues.
 """
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -69,6 +70,7 @@ class HiFTGenerator:
         self.num_upsamples = len(self.cfg.upsample_rates)
         self._loaded = False
         self._ws: Dict[tuple, dict] = {}
+        self.use_stage_abi = os.environ.get("CV_HIFT_STAGE_ABI", "1") != "0"   # decode composed by cv_hift_decode_enqueue
 
     # -- torch.nn.Module-like surface used by cli/model.py:72-81
     def to(self, *a, **k):
@@ -218,8 +220,77 @@ class HiFTGenerator:
         return self._decode_cl(ws, B, T, s2)
 
     def _decode_cl(self, ws, B, T, s2):
+        if self.use_stage_abi:
+            # stage-level ABI: the library composes the whole decode from a descriptor (cv_hift_decode_enqueue: one foreign call
+            # instead of ~100); _decode_cl_impl stays as the cross-check of the C composition (tests/test_hift_gpu.py)
+            from . import _lib as L
+            import ctypes as C
+            ent = ws.get("_desc")
+            if ent is None:
+                ent = ws["_desc"] = self.decode_desc(ws, B, T)
+            desc = ent[0]
+            desc.gemm_dtype = L.CV_F32X3 if (self.dtype == torch.float32 and self.f32_products == "bf16x3") else L.TORCH_DT[self.dtype]
+            desc.s = s2.data_ptr()
+            ops._req_cuda(s2)
+            L.check(L.lib().cv_hift_decode_enqueue(C.byref(desc), L.stream_ptr()), "cv_hift_decode_enqueue")
+            return ws["wav"]
         with ops.f32_products(self.f32_products):
             return self._decode_cl_impl(ws, B, T, s2)
+
+    def decode_desc(self, ws, B, T):
+        """cv_hift_decode_desc over this workspace (include/cosyvoice_amd.h) + the host arrays it points to."""
+        from . import _lib as L
+        import ctypes as C
+        cfg = self.cfg
+        keep = []
+
+        def conv(c, cin):
+            h = L.HiftConv()
+            h.w, h.b = c.w.data_ptr(), (c.b.data_ptr() if c.b is not None else None)
+            h.k, h.cin, h.cout, h.dilation, h.pad_left, h.stride = c.k, cin, c.cout, c.dilation, c.pad_left, c.stride
+            return h
+
+        def resblock(rb, ch):
+            units = (L.HiftResunit * len(rb))()
+            keep.append(units)
+            for j, blk in enumerate(rb):
+                units[j].c1, units[j].c2 = conv(blk["c1"], ch), conv(blk["c2"], ch)
+                units[j].a1, units[j].a2 = blk["a1"].data_ptr(), blk["a2"].data_ptr()
+            r = L.HiftResblock()
+            r.units, r.n_units = units, len(rb)
+            return r
+
+        d = L.HiftDecodeDesc()
+        d.dtype, d.B, d.T, d.S = L.TORCH_DT[self.dtype], B, T, T * cfg.total_upsample
+        d.n_stages, d.n_kernels, d.stft_ld, d.hop = self.num_upsamples, self.num_kernels, self._stft_ld, cfg.hop_len
+        d.lrelu_slope, d.audio_limit = cfg.lrelu_slope, cfg.audio_limit
+        d.conv_pre = conv(self.conv_pre, ws["mel_cl"].shape[2])
+        stages = (L.HiftStage * self.num_upsamples)()
+        keep.append(stages)
+        nk = self.num_kernels
+        for i in range(self.num_upsamples):
+            g, up = stages[i], self.ups[i]
+            t_out, c = ws["lens"][i], ws["chans"][i]
+            ph = (L.HiftPhase * up.u)()
+            keep.append(ph)
+            for r, (wp, ntaps, cr) in enumerate(up.phases):
+                ph[r].w, ph[r].ntaps, ph[r].tap_base = wp.data_ptr(), ntaps, cr
+            g.phases, g.up_b, g.u, g.up_cin = ph, up.b.data_ptr(), up.u, up.cin
+            g.source_down = conv(self.source_downs[i], self._stft_ld)
+            g.source_rb = resblock(self.source_resblocks[i], c)
+            rbs = (L.HiftResblock * nk)(*[resblock(rb, c) for rb in self.resblocks[i * nk:(i + 1) * nk]])
+            xa = (C.c_void_p * nk)(*[t.data_ptr() for t in ws[f"xa{i}"]])
+            keep += [rbs, xa]
+            g.rbs, g.xa, g.t_out, g.c = rbs, xa, t_out, c
+            g.x32, g.r0, g.r1 = ws[f"x{i}"].data_ptr(), ws[f"r{i}"][0].data_ptr(), ws[f"r{i}"][1].data_ptr()
+            g.ta, g.ra = ws[f"ta{i}"].data_ptr(), ws[f"ra{i}"].data_ptr()
+            g.acc0, g.acc1 = ws[f"acc{i}"][0].data_ptr(), ws[f"acc{i}"][1].data_ptr()
+            g.si0, g.si1, g.out = ws[f"si{i}"][0].data_ptr(), ws[f"si{i}"][1].data_ptr(), ws[f"out{i}"].data_ptr()
+        d.stages = stages
+        d.conv_post = conv(self.conv_post, ws["chans"][-1])
+        d.mel_cl, d.stft, d.a_pre = ws["mel_cl"].data_ptr(), ws["stft"].data_ptr(), ws["a_pre"].data_ptr()
+        d.post, d.wav = ws["post"].data_ptr(), ws["wav"].data_ptr()
+        return d, keep
 
     def _decode_cl_impl(self, ws, B, T, s2):
         cfg = self.cfg

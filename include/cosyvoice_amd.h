@@ -458,6 +458,44 @@ int cv_flow_euler_graph_create(const cv_flow_solver_desc* d, void* capture_strea
 int cv_flow_euler_graph_launch(void* graph, void* stream);
 int cv_flow_euler_graph_destroy(void* graph);
 
+/* cv_hift_decode_*: HiFTGenerator.decode (hifigan/generator.py:349-381) behind one call — source STFT -> conv_pre ->
+ * n_stages x [source_downs + source_resblocks, ups (ConvTranspose1d as u phase GEMMs, reflect pad on the last stage) + source
+ * fusion, num_kernels parallel ResBlocks (Snake activations, mean) + leaky-relu] -> conv_post -> exp / sin -> iSTFT -> clamp.
+ * Every conv is a cv_gemm launch over channels-last tensors with the activation / residual / mean fused into its epilogue.
+ * `dtype` = element type of the activation tensors and weights (CV_F32 for the reference-exact vocoder); `gemm_dtype` = what
+ * cv_gemm multiplies in (CV_F32 exact, CV_F32X3 = bf16 hi/lo split products, or the 16-bit dtype).
+ * `stages`, every `units` / `rbs` / `phases` / `xa` array are HOST arrays read at enqueue / capture time only. */
+typedef struct cv_hift_conv {        /* channels-last Conv1d: w [cout][k*cin] with k index = tap*cin + ci; cin = channel pitch of its input */
+  const void* w; const float* b; int32_t k, cin, cout, dilation, pad_left, stride;
+} cv_hift_conv;
+typedef struct cv_hift_resunit { cv_hift_conv c1, c2; const float* a1; const float* a2; } cv_hift_resunit;   /* Snake alphas [C] */
+typedef struct cv_hift_resblock { const cv_hift_resunit* units; int32_t n_units, reserved; } cv_hift_resblock;
+typedef struct cv_hift_phase { const void* w; int32_t ntaps, tap_base; } cv_hift_phase;   /* w [c][ntaps*up_cin] */
+typedef struct cv_hift_stage {
+  const cv_hift_phase* phases; const float* up_b; int32_t u, up_cin;
+  cv_hift_conv source_down; cv_hift_resblock source_rb;
+  const cv_hift_resblock* rbs;       /* [n_kernels] */
+  int32_t t_out, c;                  /* frames and channels after this stage */
+  /* workspace, all [B][t_out][c]: x32, r0/r1, acc0/acc1, si0/si1 fp32; xa[n_kernels], ta, ra, out `dtype` */
+  float* x32; void* const* xa; float* r0; float* r1; void* ta; void* ra; float* acc0; float* acc1; float* si0; float* si1; void* out;
+} cv_hift_stage;
+typedef struct cv_hift_decode_desc {
+  int32_t dtype, gemm_dtype, B, T, S, n_stages, n_kernels, stft_ld, hop; float lrelu_slope, audio_limit;
+  cv_hift_conv conv_pre, conv_post;
+  const cv_hift_stage* stages;
+  const void* mel_cl;                /* [B][T][conv_pre.cin] `dtype` (cv_to_channels_last of the mel) */
+  const float* s;                    /* [B][S] source signal */
+  void* stft;                        /* [B][S/hop + 1][stft_ld] `dtype` */
+  void* a_pre;                       /* [B][T][conv_pre.cout] `dtype` */
+  float* post;                       /* [B][t_last][stft_ld] fp32 */
+  float* wav;                        /* [B][(t_last - 1) * hop] fp32 output */
+} cv_hift_decode_desc;
+int cv_sizeof_hift_decode_desc(void);
+int cv_sizeof_hift_stage(void);
+int cv_sizeof_hift_resunit(void);
+int cv_hift_decode_enqueue(const cv_hift_decode_desc* d, void* stream);
+int cv_hift_decode_graph_create(const cv_hift_decode_desc* d, void* capture_stream, void** graph_out);
+
 int cv_sizeof_gemm_params(void);
 int cv_sizeof_norm_params(void);
 int cv_sizeof_attn_params(void);
