@@ -153,8 +153,8 @@ def main():
                     help="CU slots per XCD (of 32) owned by the decode loops while they overlap flow+HiFT; 0 = no partition")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo only to rehearse the multi-process path with several ranks on ONE GPU")
-    ap.add_argument("--llm-merge", type=int, default=2,
-                    help="consecutive 8-utterance batches decoded by one token loop (2: 16 rows share every weight stream)")
+    ap.add_argument("--llm-merge", type=int, default=4,
+                    help="consecutive 8-utterance batches decoded by one token loop (4: 32 rows = two 16-row MFMA groups share every weight stream)")
     ap.add_argument("--llm-loops", type=int, default=2,
                     help="concurrent decode loops (one utterance batch each, own KV caches) on the decode CUs")
     args = ap.parse_args()
@@ -440,18 +440,20 @@ def measure_decode_roofline(llm, lc, rows=UTT_PER_GPU):
     dur = ev_time(g.launch, 50, warm=2) / len(lay)
     g.destroy()
     if split:
-        alg = 2 * I * H * 2 + B * H * 2 + npart * 16 * 4 + B * I * 2   # packed bf16 weights + bf16 rows + partial sums + bf16 SwiGLU out
+        alg = 2 * I * H * 2 + B * H * 2 + npart * (16 if B <= 16 else 32) * 4 + B * I * 2   # packed bf16 weights + bf16 rows + partial sums + bf16 SwiGLU out
     else:
         alg = 2 * I * H * 2 + B * H * 4 + H * 4 + B * I * 2   # packed bf16 weights + fp32 residual rows + gamma + bf16 SwiGLU out
     traffic = None
     pmc = os.path.join(ROOT, "profiles", ("r01_roofline_pmc_split_b%d.json" % B) if split else
                        ("r01_roofline_pmc.json" if B <= 8 else "r01_roofline_pmc_b16.json"))
+    if split and os.path.exists(os.path.join(ROOT, "profiles", "r02_roofline_pmc_split_b%d.json" % B)):
+        pmc = os.path.join(ROOT, "profiles", "r02_roofline_pmc_split_b%d.json" % B)
     if os.path.exists(pmc):  # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/roofline_pmc.py)
         try:
             traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
-    return {"bound": "hbm", "kernel": (f"skinny_kernel<bf16,TPW=2,no prologue,U=7,RS> (decode gate/up, split RMSNorm: 1/rms in the epilogue, + SwiGLU), {B} rows" if split else
+    return {"bound": "hbm", "kernel": (f"skinny_kernel<bf16,TPW=2,no prologue,U=7,RS{',MR=2' if B > 16 else ''}> (decode gate/up, split RMSNorm: 1/rms in the epilogue, + SwiGLU), {B} rows" if split else
                        f"skinny_kernel<bf16,TPW=2,norm,TPR={32 if B <= 8 else 16},U=7> (decode gate/up + RMSNorm prologue + SwiGLU), {B} rows"),
             "achieved": round(alg / dur / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg / dur / 8e12, 4),
             "traffic": traffic, "bytes_per_launch": alg, "avg_launch_us": round(dur * 1e6, 3)}

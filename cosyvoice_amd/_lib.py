@@ -149,7 +149,7 @@ class LlmLayer(C.Structure):
 class LlmStepDesc(C.Structure):
     _fields_ = [
         ("dtype", _i32), ("B", _i32), ("num_layers", _i32), ("hidden", _i32), ("num_heads", _i32), ("num_kv_heads", _i32),
-        ("inter", _i32), ("ctx_max", _i32), ("down_ksplit", _i32), ("rms_eps", _f32),
+        ("inter", _i32), ("ctx_max", _i32), ("down_ksplit", _i32), ("rms_eps", _f32), ("split_qkv_norm", _i32), ("reserved", _i32),
         ("layers", C.POINTER(LlmLayer)),
         ("x", _vp), ("x2", _vp), ("xn", _vp), ("xb", _vp), ("ssp", _vp), ("n_ssp", _i32), ("qkv", _vp), ("ao", _vp), ("h", _vp),
         ("slabs", _vp), ("logits", _vp), ("vpad", _i32), ("rope_table", _vp), ("g_final", _vp), ("p_dec", _vp), ("dec_b", _vp),

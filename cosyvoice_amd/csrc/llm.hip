@@ -45,11 +45,15 @@ __global__ __launch_bounds__(256) void pack_skinny_kernel(const uint16_t* W, uin
 // leaves the decode loop its 304 workgroups ran as two rounds (11.2 us instead of 7.3).  Gamma is staged through LDS and
 // read back just in time, the K = 896 slices use clamp-free immediate-offset loads (U = 7), and the kernel is bounded to
 // 168 VGPRs = three workgroups per CU: one round on 104 CUs, 16 stragglers on 96.
-template <int DT, int TPW, int NORM, int TPR, int U, bool RS = false>   // RS: consumer half of a split RMSNorm (rs_part)
+// MR = 16-row groups of activation rows (M <= 16 * MR): every weight fragment a wave has loaded feeds MR MFMAs, so 32 rows (four
+// 8-utterance batches in one token loop) cost ONE weight stream.  Plain-row forms only (NORM == 0: beyond 8 rows the input norm is
+// its own launch); the split-norm partial sums are then pitched 16 * MR floats per part.
+template <int DT, int TPW, int NORM, int TPR, int U, bool RS = false, int MR = 1>   // RS: consumer half of a split RMSNorm (rs_part)
 __global__ __launch_bounds__(256, ((TPW == 2 && TPR >= 32) ? 3 : 2)) void skinny_kernel(const cv_skinny_params p) {
+  static_assert(MR == 1 || NORM == 0, "row groups: plain activation rows only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float (*red)[TPW][64][4] = (float (*)[TPW][64][4])smem;           // [4][TPW][64][4]
-  char* aimg = smem + 4 * TPW * 64 * 4 * sizeof(float);             // NORM: [nks][64 lanes][16 B]
+  float (*red)[TPW * MR][64][4] = (float (*)[TPW * MR][64][4])smem;   // [4][TPW * MR][64][4]
+  char* aimg = smem + 4 * TPW * MR * 64 * 4 * sizeof(float);          // NORM: [nks][64 lanes][16 B]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int nks = p.K >> 5;
   const int per = (nks + p.ksplit - 1) / p.ksplit;
@@ -78,31 +82,41 @@ __global__ __launch_bounds__(256, ((TPW == 2 && TPR >= 32) ? 3 : 2)) void skinny
 
   // mode 1 (out += A W^T): the residual values this lane will update are fetched now, with the weights, instead of
   // after the reduction (one dependent HBM round trip less on the kernel's critical path)
-  float resid[TPW][4];
+  float resid[MR][TPW][4];
 #pragma unroll
-  for (int t = 0; t < TPW; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) resid[t][r] = 0.f;
-  if (p.mode == 1 && wid == 0) {
-    const int m = min(lane & 15, p.M - 1);
+  for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        resid[t][r] = p.out_f32[(int64_t)m * p.ldo + min((tile0 + t) * 16 + 4 * (lane >> 4) + r, p.N - 1)];
+      for (int r = 0; r < 4; ++r) resid[mr][t][r] = 0.f;
+  if (p.mode == 1 && wid == 0) {
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+      const int m = min((lane & 15) + 16 * mr, p.M - 1);
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          resid[mr][t][r] = p.out_f32[(int64_t)m * p.ldo + min((tile0 + t) * 16 + 4 * (lane >> 4) + r, p.N - 1)];
+    }
   }
   // consumer half of the split RMSNorm: the producer's per-workgroup partial sums of squares of this lane's row, fetched with
   // the weights and summed in fixed order; 1/rms is applied in the epilogue
   // (lane (m, g) takes partial rows g, g + 4, ...: one batch of 16 independent loads issued ahead of the weight stream and only
   // consumed after the MFMAs; n_rs_part <= 64)
-  float rs_p[RS ? 16 : 1];
+  float rs_p[MR][RS ? 16 : 1];
   if constexpr (RS) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) rs_p[j] = 0.f;
-    if (wid == 0) {
-      const int m = min(lane & 15, p.M - 1), g4 = lane >> 4;
+    for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) rs_p[j] = p.rs_part[min(g4 + 4 * j, p.n_rs_part - 1) * 16 + m];
+      for (int j = 0; j < 16; ++j) rs_p[mr][j] = 0.f;
+    if (wid == 0) {
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr) {
+        const int m = min((lane & 15) + 16 * mr, p.M - 1), g4 = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) rs_p[mr][j] = p.rs_part[min(g4 + 4 * j, p.n_rs_part - 1) * (16 * MR) + m];
+      }
     }
   }
 
@@ -183,61 +197,87 @@ __global__ __launch_bounds__(256, ((TPW == 2 && TPR >= 32) ? 3 : 2)) void skinny
   } else {
     load_w(w0);
   }
+  // the partial sums were issued ahead of the weights and return ahead of them (loads return in order): fold them now, under the
+  // weight stream's latency, instead of carrying 16 registers per row group through the MFMA loop
+  float rs_sum[MR];
+#pragma unroll
+  for (int mr = 0; mr < MR; ++mr) rs_sum[mr] = 0.f;
+  if constexpr (RS) {
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) rs_sum[mr] += ((lane >> 4) + 4 * j < p.n_rs_part) ? rs_p[mr][j] : 0.f;
+  }
 
   // rows >= M are not fetched (their lanes re-read row M-1, the same cache lines, and are masked to zero): for M = 8 that
   // halves the activation traffic, which per workgroup is as large as the weight slice itself
-  const uint16_t* Arow = (NORM != 0) ? nullptr : (const uint16_t*)p.A + (int64_t)min(lane & 15, p.M - 1) * p.lda + 8 * (lane >> 4);
-  const uint32_t rowmask = (lane & 15) < p.M ? 0xFFFFFFFFu : 0u;
-  f32x4_t acc[TPW];
+  const uint16_t* Arow[MR];
+  uint32_t rowmask[MR];
 #pragma unroll
-  for (int t = 0; t < TPW; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int mr = 0; mr < MR; ++mr) {
+    Arow[mr] = (NORM != 0) ? nullptr : (const uint16_t*)p.A + (int64_t)min((lane & 15) + 16 * mr, p.M - 1) * p.lda + 8 * (lane >> 4);
+    rowmask[mr] = (lane & 15) + 16 * mr < p.M ? 0xFFFFFFFFu : 0u;
+  }
+  f32x4_t acc[TPW][MR];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) acc[t][mr] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   for (int ks = w0; ks < w1; ks += U) {
     if (ks != w0) load_w(ks);
-    uint4 a[U];
+    uint4 a[MR][U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      // unconditional clamped load, masked to zero beyond the slice (the clamped weight fragment then contributes 0)
-      const bool ok = (U == 7) || (ks + u < w1);
-      const int kk = ok ? ks + u : max(w1 - 1, 0);
-      uint4 t;
-      if constexpr (NORM != 0) t = *(const uint4*)(aimg + ((kk * 64 + lane) << 4));
-      else t = *(const uint4*)(Arow + kk * 32);
-      const uint32_t msk = ok ? ((NORM != 0) ? 0xFFFFFFFFu : rowmask) : 0u;
-      a[u] = make_uint4(t.x & msk, t.y & msk, t.z & msk, t.w & msk);
-    }
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        // unconditional clamped load, masked to zero beyond the slice (the clamped weight fragment then contributes 0)
+        const bool ok = (U == 7) || (ks + u < w1);
+        const int kk = ok ? ks + u : max(w1 - 1, 0);
+        uint4 t;
+        if constexpr (NORM != 0) t = *(const uint4*)(aimg + ((kk * 64 + lane) << 4));
+        else t = *(const uint4*)(Arow[mr] + kk * 32);
+        const uint32_t msk = ok ? ((NORM != 0) ? 0xFFFFFFFFu : rowmask[mr]) : 0u;
+        a[mr][u] = make_uint4(t.x & msk, t.y & msk, t.z & msk, t.w & msk);
+      }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int t = 0; t < TPW; ++t) acc[t] = mfma_block<DT>(w[t][u], a[u], acc[t]);
+      for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) acc[t][mr] = mfma_block<DT>(w[t][u], a[mr][u], acc[t][mr]);
   }
 #pragma unroll
-  for (int t = 0; t < TPW; ++t) {
-    red[wid][t][lane][0] = acc[t][0]; red[wid][t][lane][1] = acc[t][1];
-    red[wid][t][lane][2] = acc[t][2]; red[wid][t][lane][3] = acc[t][3];
-  }
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+      red[wid][t * MR + mr][lane][0] = acc[t][mr][0]; red[wid][t * MR + mr][lane][1] = acc[t][mr][1];
+      red[wid][t * MR + mr][lane][2] = acc[t][mr][2]; red[wid][t * MR + mr][lane][3] = acc[t][mr][3];
+    }
   __syncthreads();
   if (wid != 0) return;
+  const int g = lane >> 4;
+#pragma unroll
+  for (int mr = 0; mr < MR; ++mr) {
   float v[TPW][4];
 #pragma unroll
   for (int t = 0; t < TPW; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[t][r] = red[0][t][lane][r] + red[1][t][lane][r] + red[2][t][lane][r] + red[3][t][lane][r];
+    for (int r = 0; r < 4; ++r)
+      v[t][r] = red[0][t * MR + mr][lane][r] + red[1][t * MR + mr][lane][r] + red[2][t * MR + mr][lane][r] + red[3][t * MR + mr][lane][r];
 
-  const int m = lane & 15, g = lane >> 4;
-  if (m >= p.M) return;
+  const int m = (lane & 15) + 16 * mr;
+  const bool live = m < p.M;   // (dead rows run the arithmetic on zeros and store nothing: the row sums below need every lane)
   if (p.mode == 2) {
     if constexpr (TPW == 2) {
       const int nb = tile0 * 16 + 4 * g;          // gate tile columns in packed order
       const int hcol = (tile0 >> 1) * 16 + 4 * g;  // output column
       float rstd = 1.f;
       if constexpr (RS) {
-        float rs_sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) rs_sum += (g + 4 * j < p.n_rs_part) ? rs_p[j] : 0.f;
-        rs_sum += __shfl_xor(rs_sum, 16, 64);
-        rs_sum += __shfl_xor(rs_sum, 32, 64);
-        rstd = rsqrtf(rs_sum / (float)p.K + p.rs_eps);
+        float rs_t = rs_sum[mr];
+        rs_t += __shfl_xor(rs_t, 16, 64);
+        rs_t += __shfl_xor(rs_t, 32, 64);
+        rstd = rsqrtf(rs_t / (float)p.K + p.rs_eps);
       }
       float h[4];
 #pragma unroll
@@ -249,9 +289,9 @@ __global__ __launch_bounds__(256, ((TPW == 2 && TPR >= 32) ? 3 : 2)) void skinny
       uint2 u;
       u.x = pack2<DT>(h[0], h[1]);
       u.y = pack2<DT>(h[2], h[3]);
-      *(uint2*)((uint16_t*)p.out_act + (int64_t)m * p.ldoa + hcol) = u;
+      if (live) *(uint2*)((uint16_t*)p.out_act + (int64_t)m * p.ldoa + hcol) = u;
     }
-    return;
+    continue;
   }
   float ssq = 0.f;
 #pragma unroll
@@ -260,11 +300,11 @@ __global__ __launch_bounds__(256, ((TPW == 2 && TPR >= 32) ? 3 : 2)) void skinny
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = nb + r;
-      if (n >= p.N) continue;
+      if (n >= p.N || !live) continue;
       float o = v[t][r];
       if (p.bias && blockIdx.y == 0) o += p.bias[n];
       if (p.mode == 1) {
-        const float nx = resid[t][r] + o;
+        const float nx = resid[mr][t][r] + o;
         p.out_f32[(int64_t)m * p.ldo + n] = nx;
         if (p.xb_out) {   // producer half of the split RMSNorm
           ((uint16_t*)p.xb_out)[(int64_t)m * p.ldxb + n] = Elem16<DT>::from_f32(nx);
@@ -278,8 +318,9 @@ __global__ __launch_bounds__(256, ((TPW == 2 && TPR >= 32) ? 3 : 2)) void skinny
   if (p.mode == 1 && p.ss_part) {   // lanes m, m + 16, m + 32, m + 48 hold the four column groups of row m (all active together)
     ssq += __shfl_xor(ssq, 16, 64);
     ssq += __shfl_xor(ssq, 32, 64);
-    if (g == 0) p.ss_part[blockIdx.x * 16 + m] = ssq;
+    if (g == 0 && live) p.ss_part[blockIdx.x * (16 * MR) + m] = ssq;
   }
+  }   // mr
 }
 
 // =========================================================================================== streaming skinny GEMM
@@ -1241,7 +1282,8 @@ extern "C" int cv_skinny_gemm(const cv_skinny_params* pp, void* stream) {
   if (!pp) return CV_ERR_ARG;
   cv_skinny_params p = *pp;
   const bool norm = p.ngamma != nullptr;
-  if (p.M <= 0 || p.M > 16 || p.N <= 0 || p.K <= 0 || (p.K & 31) || !p.Wp) return CV_ERR_ARG;
+  if (p.M <= 0 || p.M > 32 || p.N <= 0 || p.K <= 0 || (p.K & 31) || !p.Wp) return CV_ERR_ARG;
+  if (p.M > 16 && (norm || p.mode == 3)) return CV_ERR_UNSUPPORTED;   // two row groups: plain-row forms of modes 0 / 1 / 2 only
   if (!norm && (!p.A || (p.lda & 7))) return CV_ERR_ARG;
   if (norm) {
     if (!p.nx || (p.K & 63) || p.K > 1024 || (p.ldnx & 3) || p.nx_out == p.nx) return CV_ERR_ARG;
@@ -1275,6 +1317,21 @@ extern "C" int cv_skinny_gemm(const cv_skinny_params* pp, void* stream) {
   const int per_wave = ((((p.K >> 5) + p.ksplit - 1) / p.ksplit) + 3) >> 2;
   const int ngroups = ntiles / tpw;
   if (p.mode == 2 && p.rs_part && per_wave > 8) return CV_ERR_UNSUPPORTED;   // split-norm consumer: K <= 1024 only
+  if (p.M > 16) {   // 17..32 rows: two 16-row groups share every weight fragment (MR = 2); single-shot workgroups
+    dim3 grid(ngroups, p.ksplit);
+    const size_t lds = 2 * 4 * tpw * 64 * 4 * sizeof(float);
+    const bool exact7 = per_wave == 7 && ((p.K >> 5) == 28 * p.ksplit);
+    if (tpw == 2) {
+      if (!p.rs_part) return CV_ERR_UNSUPPORTED;
+      if (exact7) { DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, 2, 0, 16, 7, true, 2>), grid, dim3(256), lds, st, p)); }
+      else { DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, 2, 0, 16, 8, true, 2>), grid, dim3(256), lds, st, p)); }
+    } else if (exact7) { DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, 1, 0, 16, 7, false, 2>), grid, dim3(256), lds, st, p)); }
+    else if (per_wave <= 8) { DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, 1, 0, 16, 8, false, 2>), grid, dim3(256), lds, st, p)); }
+    else if (per_wave <= 12) { DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, 1, 0, 16, 12, false, 2>), grid, dim3(256), lds, st, p)); }
+    else { DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, 1, 0, 16, 16, false, 2>), grid, dim3(256), lds, st, p)); }
+    CV_CHECK_LAUNCH();
+    return CV_OK;
+  }
   if (per_wave > 16 || (tpw == 2 && per_wave > 8)) {
     if (norm) return CV_ERR_UNSUPPORTED;  // cannot happen: the prologue needs K <= 1024
     dim3 grid(ngroups, p.ksplit);

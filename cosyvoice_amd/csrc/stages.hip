@@ -14,17 +14,26 @@ int enqueue_step(const cv_llm_step_desc& d, hipStream_t st) {
   const int H = d.hidden, I = d.inter, KS = d.down_ksplit;
   const int q_dim = d.num_heads * 64, kv_dim = d.num_kv_heads * 64, qkv_dim = q_dim + 2 * kv_dim;
   const float scale = 0.125f;   // 1 / sqrt(64)
+  const int RP = d.B <= 16 ? 16 : 32;   // row pitch of the split-K slabs (one or two 16-row MFMA groups)
   float* cur = d.x;
-  float* nxt = d.x2;
+  float* nxt = d.split_qkv_norm ? d.x : d.x2;   // split form: residual updated in place
   for (int li = 0; li < d.num_layers; ++li) {
     const cv_llm_layer& L = d.layers[li];
-    {   // RMSNorm(input_layernorm) of (residual + previous down-projection slabs) -> QKV; workgroup (0,0) stores the summed residual
+    if (d.split_qkv_norm) {   // one workgroup per row: residual += slabs, normalised 16-bit row; then QKV over plain rows
+      if (int rc = cv_rmsnorm_reduce(cur, H, li > 0 ? d.slabs : nullptr, li > 0 ? KS : 0, RP * (int64_t)H, H, L.g_in, d.rms_eps, d.xn, H,
+                                     d.dtype, d.B, H, st)) return rc;
+      cv_skinny_params p{};
+      p.dtype = d.dtype; p.M = d.B; p.N = qkv_dim; p.K = H;
+      p.A = d.xn; p.lda = H; p.Wp = L.p_qkv; p.bias = L.bqkv; p.ksplit = 1; p.mode = 0;
+      p.out_f32 = d.qkv; p.ldo = qkv_dim;
+      if (int rc = cv_skinny_gemm(&p, st)) return rc;
+    } else {   // RMSNorm(input_layernorm) of (residual + previous down-projection slabs) -> QKV; workgroup (0,0) stores the summed residual
       cv_skinny_params p{};
       p.dtype = d.dtype; p.M = d.B; p.N = qkv_dim; p.K = H;
       p.A = d.xn; p.lda = H; p.Wp = L.p_qkv; p.bias = L.bqkv; p.ksplit = 1; p.mode = 0;
       p.out_f32 = d.qkv; p.ldo = qkv_dim;
       p.nx = cur; p.ldnx = H; p.ngamma = L.g_in; p.neps = d.rms_eps; p.nx_out = nxt;
-      if (li > 0) { p.nslabs = d.slabs; p.n_nslab = KS; p.nslab_stride = 16 * (int64_t)H; p.ld_nslab = H; }
+      if (li > 0) { p.nslabs = d.slabs; p.n_nslab = KS; p.nslab_stride = RP * (int64_t)H; p.ld_nslab = H; }
       if (int rc = cv_skinny_gemm(&p, st)) return rc;
     }
     if (int rc = cv_decode_attention(d.xn, H, L.kcache, L.vtcache, d.sample.pos, 1, d.ao, q_dim, d.B, d.num_heads, d.num_kv_heads,
@@ -49,12 +58,12 @@ int enqueue_step(const cv_llm_step_desc& d, hipStream_t st) {
       cv_skinny_params p{};
       p.dtype = d.dtype; p.M = d.B; p.N = H; p.K = I;
       p.A = d.h; p.lda = I; p.Wp = L.p_down; p.ksplit = KS; p.mode = 0;
-      p.out_f32 = d.slabs; p.ldo = H; p.slab_stride = 16 * (int64_t)H;
+      p.out_f32 = d.slabs; p.ldo = H; p.slab_stride = RP * (int64_t)H;
       if (int rc = cv_skinny_gemm(&p, st)) return rc;
     }
     float* t = cur; cur = nxt; nxt = t;
   }
-  if (int rc = cv_rmsnorm_reduce(cur, H, d.slabs, KS, 16 * (int64_t)H, H, d.g_final, d.rms_eps, d.xn, H, d.dtype, d.B, H, st)) return rc;
+  if (int rc = cv_rmsnorm_reduce(cur, H, d.slabs, KS, RP * (int64_t)H, H, d.g_final, d.rms_eps, d.xn, H, d.dtype, d.B, H, st)) return rc;
   {   // speech-token head
     cv_skinny_params p{};
     p.dtype = d.dtype; p.M = d.B; p.N = d.out_vocab; p.K = H;
@@ -71,7 +80,7 @@ int enqueue_step(const cv_llm_step_desc& d, hipStream_t st) {
 int check_desc(const cv_llm_step_desc* d) {
   if (!d || !d->layers || d->num_layers <= 0) return CV_ERR_ARG;
   if (d->dtype != CV_BF16 && d->dtype != CV_F16) return CV_ERR_UNSUPPORTED;
-  if (d->B <= 0 || d->B > 16 || d->down_ksplit < 2 || (d->hidden & 63) || d->num_kv_heads <= 0 || d->num_heads % d->num_kv_heads) return CV_ERR_UNSUPPORTED;
+  if (d->B <= 0 || d->B > 32 || (d->B > 16 && !d->split_qkv_norm) || d->down_ksplit < 2 || (d->hidden & 63) || d->num_kv_heads <= 0 || d->num_heads % d->num_kv_heads) return CV_ERR_UNSUPPORTED;
   if (!d->x || !d->x2 || !d->xn || !d->xb || !d->ssp || !d->qkv || !d->ao || !d->h || !d->slabs || !d->logits || !d->rope_table ||
       !d->g_final || !d->p_dec || !d->sample.pos || !d->sample.step || !d->sample.n_emitted || !d->sample.finished ||
       !d->sample.out_tokens || !d->sample.emb_table || !d->sample.min_len || !d->sample.max_len) return CV_ERR_ARG;

@@ -39,7 +39,8 @@ class Qwen2LM:
                  win_size: int = 10, tau_r: float = 0.1):
         self.cfg = cfg or LlmConfig.full()
         self.dtype, self.device = dtype, torch.device(device)
-        assert max_batch <= 16 and ctx_max % 64 == 0
+        assert max_batch <= 32 and ctx_max % 64 == 0
+        self.R = 16 if max_batch <= 16 else 32   # rows of every per-step state buffer (the skinny kernels take <= 16 rows per MFMA row group, <= 2 groups)
         self.max_batch, self.ctx_max, self.max_out = max_batch, ctx_max, max_out
         self.top_p, self.top_k, self.win_size, self.tau_r = top_p, top_k, win_size, tau_r
         # repetition fallback of the sampler: 0 = ras_sampling (random over the full distribution, utils/common.py:106-112),
@@ -127,13 +128,14 @@ class Qwen2LM:
         z = lambda *s, dtype=torch.float32: torch.zeros(*s, device=dev, dtype=dtype)
         self.Vpad = _round_up(cfg.out_vocab, 16)
         MB = self.max_batch
-        self.st = dict(x=z(16, H), x2=z(16, H), xn=z(16, H, dtype=dt), xb=z(16, H, dtype=dt), ssp=z((H + 15) // 16, 16), qkv=z(16, qkv_dim), q=z(16, cfg.q_dim, dtype=dt),
-                       ao=z(16, cfg.q_dim, dtype=dt), h=z(16, I, dtype=dt), slabs=z(self.DOWN_KSPLIT, 16, H),
-                       logits=z(16, self.Vpad), pos=z(16, dtype=torch.int32), step=z(16, dtype=torch.int32),
-                       n_emitted=z(16, dtype=torch.int32), finished=z(16, dtype=torch.int32), min_len=z(16, dtype=torch.int32),
-                       max_len=z(16, dtype=torch.int32), out_tokens=z(16, self.max_out, dtype=torch.int32),
-                       forced=torch.full((16, self.max_out), -1, device=dev, dtype=torch.int32),
-                       uniforms=z(16, 101, 2), nonce=z(2, dtype=torch.int64))
+        R = self.R
+        self.st = dict(x=z(R, H), x2=z(R, H), xn=z(R, H, dtype=dt), xb=z(R, H, dtype=dt), ssp=z((H + 15) // 16, 32), qkv=z(R, qkv_dim), q=z(R, cfg.q_dim, dtype=dt),
+                       ao=z(R, cfg.q_dim, dtype=dt), h=z(R, I, dtype=dt), slabs=z(self.DOWN_KSPLIT, 32, H),
+                       logits=z(R, self.Vpad), pos=z(R, dtype=torch.int32), step=z(R, dtype=torch.int32),
+                       n_emitted=z(R, dtype=torch.int32), finished=z(R, dtype=torch.int32), min_len=z(R, dtype=torch.int32),
+                       max_len=z(R, dtype=torch.int32), out_tokens=z(R, self.max_out, dtype=torch.int32),
+                       forced=torch.full((R, self.max_out), -1, device=dev, dtype=torch.int32),
+                       uniforms=z(R, 101, 2), nonce=z(2, dtype=torch.int64))
         # per-layer caches in the fragment-tiled layout of the fused decode attention (cv_kv_retile); the prefill writes one
         # layer at a time into the row-major scratch pair (what cv_rope_append / cv_attention use) and re-tiles it
         self.kcache = [z(MB, cfg.num_kv_heads, self.ctx_max, 64, dtype=dt) for _ in range(cfg.num_layers)]
@@ -169,6 +171,16 @@ class Qwen2LM:
         p.nonce = st["nonce"].data_ptr()
         return p
 
+    @staticmethod
+    def _rp(B):
+        """Row pitch of the split-K slabs / partial-sum planes of a step over B rows (one or two 16-row MFMA groups)."""
+        return 16 if B <= 16 else 32
+
+    def _split_qkv(self, B):
+        """QKV RMSNorm as its own launch (see _decode_step): CV_SPLIT_QKV_NORM=0/1 forces it, default = more than 8 rows."""
+        v = os.environ.get("CV_SPLIT_QKV_NORM")
+        return self.split_norm and self.DOWN_KSPLIT >= 2 and ((v == "1") if v in ("0", "1") else B > 8)
+
     def _step_desc(self, B, use_forced, use_uniforms):
         """The decode step as ONE descriptor for the stage-level ABI (cv_llm_step_graph_create): every weight / state pointer of
         the step.  The layer array is kept alive on the object (the library reads it at capture time only)."""
@@ -184,6 +196,7 @@ class Qwen2LM:
         d.dtype, d.B, d.num_layers, d.hidden = L.TORCH_DT[self.dtype], B, cfg.num_layers, cfg.hidden_size
         d.num_heads, d.num_kv_heads, d.inter, d.ctx_max = cfg.num_heads, cfg.num_kv_heads, cfg.intermediate_size, self.ctx_max
         d.down_ksplit, d.rms_eps = self.DOWN_KSPLIT, cfg.rms_eps
+        d.split_qkv_norm = int(self._split_qkv(B))
         d.layers = C.cast(arr, C.POINTER(L.LlmLayer))
         d.x, d.x2, d.xn, d.xb = st["x"].data_ptr(), st["x2"].data_ptr(), st["xn"].data_ptr(), st["xb"].data_ptr()
         d.ssp, d.n_ssp, d.qkv, d.ao, d.h = st["ssp"].data_ptr(), st["ssp"].shape[0], st["qkv"].data_ptr(), st["ao"].data_ptr(), st["h"].data_ptr()
@@ -228,11 +241,33 @@ class Qwen2LM:
             ops.rmsnorm_reduce(x, self.g_final, cfg.rms_eps, st["xn"], B)
             self._head_and_sample(B, use_forced, use_uniforms)
             return
+        if self._split_qkv(B):
+            # more than 8 rows: the QKV kernel's fused prologue (each of its 72 workgroups re-reads the fp32 residual + KS slabs of
+            # every row: 286 KB at 16 rows) costs more than a launch — one workgroup per row sums the slabs into the residual and
+            # leaves the normalised 16-bit row (cv_rmsnorm_reduce), the QKV kernel streams plain rows (16 rows on the decode loops'
+            # 64 CUs: 10.7 -> 3.4 + 4.3 us, tools/llm_kernel_bench.py); the residual is then updated in place, no ping-pong
+            x = st["x"]
+            for li, lay in enumerate(self.layers):
+                if li > 0:
+                    ops.rmsnorm_reduce(x, lay["g_in"], cfg.rms_eps, st["xn"], B, slabs=st["slabs"], nslab=KS, slab_stride=self._rp(B) * H, ld_slab=H)
+                else:
+                    ops.rmsnorm_reduce(x, lay["g_in"], cfg.rms_eps, st["xn"], B)
+                ops.skinny_gemm(st["xn"], lay["p_qkv"], B, qkv_dim, H, bias=lay["bqkv"], out_f32=st["qkv"], ldo=qkv_dim)
+                ops.decode_attention(st["q"], self.kcache[li], self.vtcache[li], st["pos"], 1, st["ao"], B, cfg.num_heads,
+                                     cfg.num_kv_heads, self.ctx_max, scale, qkv=st["qkv"], inv_freq=self.rope_table)
+                ops.skinny_gemm(st["ao"], lay["p_o"], B, H, cfg.q_dim, mode=1, out_f32=x, ldo=H,
+                                split_out=dict(xb=st["xb"], ss=st["ssp"]))
+                ops.skinny_gemm(st["xb"], lay["p_gu_g"], B, 2 * I, H, mode=2, out_act=st["h"], ldoa=I,
+                                split_in=dict(rs=st["ssp"], n=st["ssp"].shape[0], eps=cfg.rms_eps))
+                ops.skinny_gemm(st["h"], lay["p_down"], B, H, I, ksplit=KS, out_f32=st["slabs"], ldo=H, slab_stride=self._rp(B) * H, max_wgs=mw)
+            ops.rmsnorm_reduce(x, self.g_final, cfg.rms_eps, st["xn"], B, slabs=st["slabs"], nslab=KS, slab_stride=self._rp(B) * H, ld_slab=H)
+            self._head_and_sample(B, use_forced, use_uniforms)
+            return
         cur, nxt = st["x"], st["x2"]
         for li, lay in enumerate(self.layers):
             nrm = dict(x=cur, gamma=lay["g_in"], eps=cfg.rms_eps, x_out=nxt)
             if li > 0:
-                nrm.update(slabs=st["slabs"], nslab=KS, slab_stride=16 * H, ld_slab=H)
+                nrm.update(slabs=st["slabs"], nslab=KS, slab_stride=self._rp(B) * H, ld_slab=H)
             ops.skinny_gemm(st["xn"], lay["p_qkv"], B, qkv_dim, H, bias=lay["bqkv"], out_f32=st["qkv"], ldo=qkv_dim, norm=nrm)
             ops.decode_attention(st["q"], self.kcache[li], self.vtcache[li], st["pos"], 1, st["ao"], B, cfg.num_heads,
                                  cfg.num_kv_heads, self.ctx_max, scale, qkv=st["qkv"], inv_freq=self.rope_table)
@@ -248,9 +283,9 @@ class Qwen2LM:
                 ops.skinny_gemm(st["ao"], lay["p_o"], B, H, cfg.q_dim, mode=1, out_f32=nxt, ldo=H)
                 ops.skinny_gemm(st["xn"], lay["p_gu"], B, 2 * I, H, mode=2, out_act=st["h"], ldoa=I,
                                 norm=dict(x=nxt, gamma=lay["g_post"], eps=cfg.rms_eps), max_wgs=mw)
-            ops.skinny_gemm(st["h"], lay["p_down"], B, H, I, ksplit=KS, out_f32=st["slabs"], ldo=H, slab_stride=16 * H, max_wgs=mw)
+            ops.skinny_gemm(st["h"], lay["p_down"], B, H, I, ksplit=KS, out_f32=st["slabs"], ldo=H, slab_stride=self._rp(B) * H, max_wgs=mw)
             cur, nxt = nxt, cur
-        ops.rmsnorm_reduce(cur, self.g_final, cfg.rms_eps, st["xn"], B, slabs=st["slabs"], nslab=KS, slab_stride=16 * H, ld_slab=H)
+        ops.rmsnorm_reduce(cur, self.g_final, cfg.rms_eps, st["xn"], B, slabs=st["slabs"], nslab=KS, slab_stride=self._rp(B) * H, ld_slab=H)
         self._head_and_sample(B, use_forced, use_uniforms)
 
     def _step(self, B, use_forced, use_uniforms):
@@ -382,8 +417,8 @@ class Qwen2LM:
         for k in ("step", "n_emitted", "finished"):
             st[k].zero_()
         st["finished"][B:].fill_(1)
-        mn = torch.zeros(16, dtype=torch.int32)
-        mx = torch.zeros(16, dtype=torch.int32)
+        mn = torch.zeros(self.R, dtype=torch.int32)
+        mx = torch.zeros(self.R, dtype=torch.int32)
         for b in range(B):
             tl = texts[b].numel()  # text_len - prompt_text_len (llm.py:855-856)
             mn[b] = int(tl * min_token_text_ratio)
@@ -393,7 +428,7 @@ class Qwen2LM:
         st["max_len"].copy_(mx)
         use_forced = forced is not None
         if use_forced:
-            f = torch.full((16, self.max_out), -2, dtype=torch.int32)
+            f = torch.full((self.R, self.max_out), -2, dtype=torch.int32)
             for b in range(B):
                 f[b, :len(forced[b])] = torch.tensor(forced[b], dtype=torch.int32)
             st["forced"].copy_(f)
@@ -482,7 +517,7 @@ class Qwen2LM:
         st["finished"][B:].fill_(1)
         st["min_len"].fill_(0)
         st["max_len"].fill_(len(forced) + 8)
-        f = torch.full((16, self.max_out), -2, dtype=torch.int32)
+        f = torch.full((self.R, self.max_out), -2, dtype=torch.int32)
         f[0, :len(forced)] = torch.tensor(forced, dtype=torch.int32)
         st["forced"].copy_(f)
         self._assemble_inputs(ws, [text], [prompt_text], [prompt_speech], B, Lp)

@@ -9,6 +9,7 @@ The stage objects are the HIP-backed ``cosyvoice_amd.llm.Qwen2LM`` / ``flow.Caus
 ``tts_batch`` is the build's utterance-batched entry (the reference is batch-1): LLM decode batched over B
 sequences, flow batched over B CFG pairs, HiFT batched over B mels.
 """
+import os
 import threading
 import time
 import uuid
@@ -73,6 +74,7 @@ class CosyVoice2Model:
         self.llm_end_dict = {}
         self.hift_cache_dict = {}
         self._llm_spans = {}      # uuid -> [start, end] wall-clock of the request's token loop (diagnostics / tests)
+        self.overlap_hift = os.environ.get("CV_OVERLAP_HIFT", "0") != "0"   # tts_batches: HiFT of batch i on its own stream beside flow of batch i + 1 (measured SLOWER: 455 vs 548 audio-s/s — the vocoder GEMMs and the flow chain disturb each other on shared CUs; kept for experiments)
         self.pipeline_stats = None  # set to a list to collect (stage, batches, start, end) of every tts_batches job
 
     def load(self, llm_model, flow_model, hift_model):
@@ -249,7 +251,8 @@ class CosyVoice2Model:
             self._cu_partition = ([ops.masked_stream(lambda s, x: s < k) for _ in range(n_llm)],
                                   ops.masked_stream(lambda s, x: s >= k),
                                   ops.masked_stream(lambda s, x: s >= k),   # a decode loop borrowing the idle flow CUs
-                                  [ops.masked_stream(lambda s, x: s >= k) for _ in range(n_llm)])  # prefills, on the flow CUs
+                                  [ops.masked_stream(lambda s, x: s >= k) for _ in range(n_llm)],  # prefills, on the flow CUs
+                                  ops.masked_stream(lambda s, x: s >= k))   # HiFT of batch i beside the flow of batch i + 1
             self._cu_partition_key = key
         return self._cu_partition
 
@@ -258,7 +261,7 @@ class CosyVoice2Model:
         part = getattr(self, "_cu_partition", None)
         if part is not None:
             torch.cuda.synchronize()
-            flat = list(part[0]) + [part[1], part[2]] + list(part[3])
+            flat = list(part[0]) + [part[1], part[2]] + list(part[3]) + list(part[4:5])
             for st in flat:
                 ops.destroy_masked_stream(st)
         self._cu_partition, self._cu_partition_key = None, None
@@ -334,7 +337,7 @@ class CosyVoice2Model:
         import queue
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
-        llm_parts, flow_part, borrow_part, prefill_parts = self.cu_partition(k, n_llm)
+        llm_parts, flow_part, borrow_part, prefill_parts, hift_part = self.cu_partition(k, n_llm)
         est = getattr(getattr(self.flow, "decoder", None), "estimator", None)
         if est is not None:
             est.cu_budget = (32 - k) * 8   # the flow's launches run on that many CUs: its row-block kernels size their tiles for it
@@ -370,12 +373,44 @@ class CosyVoice2Model:
             finally:
                 ctxs.put((ctx, own, pf))
 
+        def hift_job(mel, mel_ready, t_job):
+            """HiFT (+ D2H) of one equal-length batch on its own stream over the flow CUs: the vocoder of batch i fills the CUs the
+            flow of batch i + 1 leaves idle (the tail round of every attention launch, tile quantisation of the row-block
+            kernels) instead of extending the flow stream's critical path (17 of a 91 ms job on all CUs)."""
+            with torch.no_grad(), torch.cuda.stream(hift_part):
+                hift_part.wait_event(mel_ready)
+                mel.record_stream(hift_part)
+                wav, _ = self.hift.inference(speech_feat=mel, cache_source=torch.zeros(1, 1, 0))
+                if to_host:
+                    res = wav.cpu(), None
+                    if self.pipeline_stats is not None:
+                        self.pipeline_stats.append(("flow", 1, t_job, time.perf_counter()))
+                    return res
+                wav = wav.clone()
+                done = torch.cuda.Event()
+                done.record(hift_part)
+                return wav, done
+
         def flow_job(b, llm_fut, idx, ready, stream):
             toks = llm_fut.result()[idx]
             t_job = time.perf_counter()
+            n_t = len(toks[0])
+            if self.overlap_hift and all(len(t) == n_t for t in toks):
+                with torch.no_grad(), torch.cuda.stream(stream):
+                    stream.wait_event(ready)
+                    stream.wait_stream(flow_part if stream is flow_full else flow_full)  # workspaces of the previous batch
+                    tok = torch.tensor(toks, dtype=torch.int32, device=self.device)
+                    mel = self.flow.inference_batch(tok, b["flow_prompt_speech_tokens"], b["prompt_speech_feats"], b["flow_embeddings"])
+                    mel = mel.contiguous().clone()   # the flow's output buffer is rewritten by the next batch
+                    mel_ready = torch.cuda.Event()
+                    mel_ready.record(stream)
+                return hift_pool.submit(hift_job, mel, mel_ready, t_job)   # one worker: vocoder workspaces are used in batch order
             with torch.no_grad(), torch.cuda.stream(stream):
                 stream.wait_event(ready)
                 stream.wait_stream(flow_part if stream is flow_full else flow_full)  # workspaces of the previous batch
+                if self.overlap_hift:
+                    hift_pool.submit(lambda: None).result()   # earlier batches' vocoder jobs are enqueued ...
+                    stream.wait_stream(hift_part)             # ... and done with the vocoder workspaces before this one uses them
                 wav = self._flow_hift(b, toks)
                 if to_host:
                     res = ([w.cpu() for w in wav] if isinstance(wav, list) else wav.cpu()), None
@@ -390,7 +425,10 @@ class CosyVoice2Model:
                 return wav, done
 
         def collect(fut):
-            wav, done = fut.result()
+            r = fut.result()
+            if hasattr(r, "result"):   # the equal-length path hands back its vocoder job
+                r = r.result()
+            wav, done = r
             if done is not None:
                 caller.wait_event(done)
             return wav
@@ -400,7 +438,8 @@ class CosyVoice2Model:
         inflight = deque()
         first = True
         merge = max(1, int(getattr(self, "llm_merge", 1)))
-        with ThreadPoolExecutor(max_workers=n_llm) as llm_pool, ThreadPoolExecutor(max_workers=1) as flow_pool:
+        with ThreadPoolExecutor(max_workers=n_llm) as llm_pool, ThreadPoolExecutor(max_workers=1) as flow_pool, \
+                ThreadPoolExecutor(max_workers=1) as hift_pool:
             while nxt is not None or inflight:
                 # keep n_llm decode loops busy plus one job queued behind them
                 while nxt is not None and len(inflight) < (n_llm + 2) * merge:

@@ -394,8 +394,13 @@ typedef struct cv_llm_layer {
 } cv_llm_layer;
 typedef struct cv_llm_step_desc {
   int32_t dtype, B, num_layers, hidden, num_heads, num_kv_heads, inter, ctx_max, down_ksplit; float rms_eps;
+  int32_t split_qkv_norm;                 /* != 0: input RMSNorm (+ slab reduce) as its own cv_rmsnorm_reduce launch, residual updated in place in x
+                                             (pays off beyond 8 rows); 0: fused into the QKV kernel's prologue, residual ping-pongs x / x2 */
+  int32_t reserved;
   const cv_llm_layer* layers;             /* host array [num_layers] */
-  float* x; float* x2;                    /* [16][hidden] fp32: input embedding of the step / residual ping-pong */
+  /* state rows: 16 for B <= 16, 32 for B <= 32 (two MFMA row groups share every weight stream; needs split_qkv_norm);
+     slabs / ssp are pitched by that row count */
+  float* x; float* x2;                    /* [rows][hidden] fp32: input embedding of the step / residual ping-pong */
   void* xn; void* xb;                     /* [16][hidden] 16-bit scratch rows */
   float* ssp; int32_t n_ssp;              /* [hidden / 16][16] partial sums of squares */
   float* qkv;                             /* [16][q_dim + 2 kv_dim] fp32 */

@@ -424,8 +424,10 @@ def test_generate_from_ready_made_prefill_embeddings():
     assert got == want
 
 
-def test_stage_abi_step_equals_python_composed_step():
-    """cv_llm_step_graph_create (the decode step composed + captured inside the library) against the same step composed launch by
+@pytest.mark.parametrize("split_qkv", ["0", "1"])
+def test_stage_abi_step_equals_python_composed_step(split_qkv, monkeypatch):
+    """(both forms of the input RMSNorm: fused into the QKV kernel's prologue / its own cv_rmsnorm_reduce launch, the >8-row default)
+    cv_llm_step_graph_create (the decode step composed + captured inside the library) against the same step composed launch by
     launch from Python: teacher-forced logits and free-running tokens (injected uniforms) bit-identical; the header's stage entry
     points are what a non-Python host would bind."""
     from cosyvoice_amd.llm import Qwen2LM
@@ -437,6 +439,7 @@ def test_stage_abi_step_equals_python_composed_step():
     ps = torch.randint(0, cfg.speech_token_size, (1, 8), generator=g, dtype=torch.int32)
     forced = torch.randint(0, cfg.speech_token_size, (9,), generator=g).tolist()
     uni = torch.rand(16, 101, 2, generator=g) * 0.98
+    monkeypatch.setenv("CV_SPLIT_QKV_NORM", split_qkv)
     outs = {}
     for abi in (True, False):
         lm = Qwen2LM(cfg, dtype=torch.bfloat16, max_batch=4, ctx_max=256, max_out=256)
@@ -448,3 +451,25 @@ def test_stage_abi_step_equals_python_composed_step():
     assert torch.equal(outs[True][0], outs[False][0])
     assert outs[True][1] == outs[False][1] and all(len(t) >= 10 for t in outs[True][1])
     assert outs[True][2] >= 1
+
+
+def test_32_row_token_loop_equals_two_16_row_loops():
+    """17..32 sequences per step run the skinny kernels with two 16-row MFMA groups per weight fragment (MR = 2: one weight stream
+    for all rows).  Every row's dot products are formed in the same order as in the one-group form, so 20 sequences decoded in one
+    loop must give exactly the tokens of the same sequences decoded as 10 + 10 (same injected uniforms per sequence)."""
+    from cosyvoice_amd.llm import Qwen2LM
+    cfg = LlmConfig.tiny()
+    sd = llm_state_dict(cfg)
+    g = torch.Generator().manual_seed(11)
+    n = 20
+    texts = [torch.randint(0, cfg.vocab_size, (1, 5 + b % 4), generator=g, dtype=torch.int32) for b in range(n)]
+    ptext = torch.randint(0, cfg.vocab_size, (1, 3), generator=g, dtype=torch.int32)
+    ps = [torch.randint(0, cfg.speech_token_size, (1, 6 + b % 3), generator=g, dtype=torch.int32) for b in range(n)]
+    uni = torch.rand(32, 101, 2, generator=g) * 0.98
+    lm32 = Qwen2LM(cfg, dtype=torch.bfloat16, max_batch=32, ctx_max=256, max_out=256).load_state_dict(sd)
+    t32 = lm32.generate_batch(texts, [ptext] * n, ps, uniforms=uni, max_steps=40)
+    lm16 = Qwen2LM(cfg, dtype=torch.bfloat16, max_batch=16, ctx_max=256, max_out=256).load_state_dict(sd)
+    ta = lm16.generate_batch(texts[:10], [ptext] * 10, ps[:10], uniforms=uni[:16], max_steps=40)
+    tb = lm16.generate_batch(texts[10:], [ptext] * 10, ps[10:], uniforms=uni[10:26], max_steps=40)
+    assert all(len(t) >= 10 for t in t32)
+    assert t32 == ta + tb

@@ -26,19 +26,27 @@ scale = 1.0 / math.sqrt(cfg.head_dim)
 x, x2 = st["x"], st["x2"]
 CAP = 0   # max_wgs passed to the skinny kernels while a graph is captured
 
+def k_qkv_plain(li, lay):   # the > 8-row form: input norm as its own launch (k_norm), plain rows into the QKV kernel
+    ops.skinny_gemm(st["xn"], lay["p_qkv"], Bn, qkv_dim, H, bias=lay["bqkv"], out_f32=st["qkv"], ldo=qkv_dim)
+def k_norm(li, lay): ops.rmsnorm_reduce(x, lay["g_in"], cfg.rms_eps, st["xn"], Bn, slabs=st["slabs"], nslab=KS, slab_stride=llm._rp(Bn) * H, ld_slab=H)
 def k_qkv(li, lay):
+    if Bn > 16: return k_qkv_plain(li, lay)
     ops.skinny_gemm(st["xn"], lay["p_qkv"], Bn, qkv_dim, H, bias=lay["bqkv"], out_f32=st["qkv"], ldo=qkv_dim,
-                    norm=dict(x=x, gamma=lay["g_in"], eps=cfg.rms_eps, x_out=x2, slabs=st["slabs"], nslab=KS, slab_stride=16 * H, ld_slab=H), max_wgs=CAP)
+                    norm=dict(x=x, gamma=lay["g_in"], eps=cfg.rms_eps, x_out=x2, slabs=st["slabs"], nslab=KS, slab_stride=llm._rp(Bn) * H, ld_slab=H), max_wgs=CAP)
 def k_attn(li, lay):
     ops.decode_attention(st["q"], llm.kcache[li], llm.vtcache[li], st["pos"], 1, st["ao"], Bn, cfg.num_heads, cfg.num_kv_heads,
                          llm.ctx_max, scale, qkv=st["qkv"], inv_freq=llm.rope_table)
 def k_o(li, lay): ops.skinny_gemm(st["ao"], lay["p_o"], Bn, H, cfg.q_dim, mode=1, out_f32=x2, ldo=H, max_wgs=CAP)
 def k_gu(li, lay):
+    if Bn > 16: return
     ops.skinny_gemm(st["xn"], lay["p_gu"], Bn, 2 * I, H, mode=2, out_act=st["h"], ldoa=I, norm=dict(x=x2, gamma=lay["g_post"], eps=cfg.rms_eps), max_wgs=CAP)
 def k_gu_nonorm(li, lay):   # ablation: the same weight stream and SwiGLU epilogue without the RMSNorm prologue
+    if Bn > 16:   # two row groups: only the split-norm consumer form exists (what the step uses)
+        return ops.skinny_gemm(st["xb"], lay["p_gu_g"], Bn, 2 * I, H, mode=2, out_act=st["h"], ldoa=I,
+                               split_in=dict(rs=st["ssp"], n=st["ssp"].shape[0], eps=cfg.rms_eps))
     ops.skinny_gemm(st["xn"], lay["p_gu"], Bn, 2 * I, H, mode=2, out_act=st["h"], ldoa=I, max_wgs=CAP)
-def k_down(li, lay): ops.skinny_gemm(st["h"], lay["p_down"], Bn, H, I, ksplit=KS, out_f32=st["slabs"], ldo=H, slab_stride=16 * H, max_wgs=CAP)
-def k_final(li, lay): ops.rmsnorm_reduce(x, llm.g_final, cfg.rms_eps, st["xn"], Bn, slabs=st["slabs"], nslab=KS, slab_stride=16 * H, ld_slab=H)
+def k_down(li, lay): ops.skinny_gemm(st["h"], lay["p_down"], Bn, H, I, ksplit=KS, out_f32=st["slabs"], ldo=H, slab_stride=llm._rp(Bn) * H, max_wgs=CAP)
+def k_final(li, lay): ops.rmsnorm_reduce(x, llm.g_final, cfg.rms_eps, st["xn"], Bn, slabs=st["slabs"], nslab=KS, slab_stride=llm._rp(Bn) * H, ld_slab=H)
 def k_head(li, lay): ops.skinny_gemm(st["xn"], llm.p_dec, Bn, cfg.out_vocab, H, bias=llm.dec_b, out_f32=st["logits"], ldo=llm.Vpad, max_wgs=CAP)
 def k_sample(li, lay):
     st["finished"].zero_()
@@ -66,8 +74,16 @@ full, part = torch.cuda.current_stream(), ops.masked_stream(lambda s_, x_: s_ < 
 configs = [(full, 0), (part, 0)]
 print("kernel      all CUs | 64 CUs")
 only = __import__('os').environ.get('LKB_ONLY')
-for name, fn, per in (("qkv", k_qkv, 24), ("attn", k_attn, 24), ("o_proj", k_o, 24), ("gate_up", k_gu, 24), ("gu_nonorm", k_gu_nonorm, 24), ("down", k_down, 24),
+for name, fn, per in (("in_norm", k_norm, 24), ("qkv_plain", k_qkv_plain, 24), ("qkv", k_qkv, 24), ("attn", k_attn, 24), ("o_proj", k_o, 24), ("gate_up", k_gu, 24), ("gu_nonorm", k_gu_nonorm, 24), ("down", k_down, 24),
                       ("final_norm", k_final, 24), ("head", k_head, 24)):
     if only and name != only: continue
     bench(name, fn, per, configs if name not in ("attn", "final_norm") else configs[:2])
 if not only: bench("head+samp", k_sample, 24, configs[:1])   # per (head + memset + sampler) triple
+
+if __import__('os').environ.get('LKB_PAIR'):
+    # the same layer's launch twice in a row: does the second one run from L2 (weights streamed with the nt policy)?
+    def pair(fn):
+        return lambda li, lay: (fn(li, lay), fn(li, lay))
+    print("pairs (us per PAIR)")
+    for name, fn in (("gate_up", k_gu_nonorm), ("down", k_down), ("o_proj", k_o)):
+        bench(name + "x2", pair(fn), 24, configs)

@@ -8,12 +8,13 @@ H, I, L = 896, 4864, 24
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 dev = 'cuda'
 torch.manual_seed(0)
-xn = torch.zeros(16, H, device=dev, dtype=torch.bfloat16); xn[:B] = torch.randn(B, H, device=dev).to(torch.bfloat16)
-x = torch.randn(16, H, device=dev); gam = torch.ones(H, device=dev)
-h = torch.zeros(16, I, device=dev, dtype=torch.bfloat16)
+R = 16 if B <= 16 else 32
+xn = torch.zeros(R, H, device=dev, dtype=torch.bfloat16); xn[:B] = torch.randn(B, H, device=dev).to(torch.bfloat16)
+x = torch.randn(R, H, device=dev); gam = torch.ones(H, device=dev)
+h = torch.zeros(R, I, device=dev, dtype=torch.bfloat16)
 packs = [ops.pack_skinny((torch.randn(2 * I, H, device=dev) / H ** 0.5).to(torch.bfloat16), interleave=True) for _ in range(L)]
 split = len(sys.argv) > 2 and sys.argv[2] == "split"      # the decode step's form: 16-bit rows + partial sums, 1/rms in the epilogue
-ssp = torch.rand(56, 16, device=dev)
+ssp = torch.rand(56, R, device=dev)
 for _ in range(5):
     for p in packs:
         if split:
