@@ -515,7 +515,7 @@ class CausalConditionalCFM:
 
         # stage-level ABI (cv_flow_euler_*): the library composes and captures the same launch sequence from a descriptor;
         # `run` stays as the eager path and as the cross-check of the C composition (tests/test_flow_gpu.py)
-        stage_abi = self.use_stage_abi and est.fused_all
+        stage_abi = self.use_stage_abi and getattr(est, "fused_all", False)   # (the v1 estimator, flow_v1.py, has no fused form)
 
         if not self.use_graph:
             run()

@@ -22,6 +22,7 @@ from .llm_phoneme import _TextEncoder
 
 class ConditionalDecoderV1(ConditionalDecoder):
     """Non-causal two-level U-Net estimator.  Same slot contract as the parent (``__call__``), same ``forward_cl`` driver."""
+    fused_all = False   # GroupNorm resnets, strided down / transposed up convs: not what cv_flow_euler_* composes
 
     def load(self, sd, prefix="decoder.estimator."):
         cfg = self.cfg
@@ -129,6 +130,7 @@ class ConditionalCFM(CausalConditionalCFM):
         self.inference_cfg_rate = cfg.inference_cfg_rate
         self._graphs: Dict[tuple, tuple] = {}
         self.use_graph = False
+        self.use_stage_abi = False   # cv_flow_euler_* composes the CosyVoice2 (causal, fused) estimator only
 
 
 class MaskedDiffWithXvec:
