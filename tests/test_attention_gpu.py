@@ -110,3 +110,37 @@ def test_fully_masked_query_rows_are_zero(dt, with_bias):
                v.float().view(B, T, H, 64).transpose(1, 2), scale, causal=True, causal_off=off, **rkw).transpose(1, 2).reshape(B, T, H * 64)
     err = (o[:, -off:] - ref[:, -off:]).abs().max().item()
     assert err < (3e-2 if dt == torch.bfloat16 else 4e-3), err
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("jump", [3.0, 7.5, 8.5, 40.0])
+def test_online_softmax_rescale_branch(dt, tol, jump):
+    """The tile step rescales its output accumulators only when some query's running max moved (wave-uniform branch).  A rare,
+    data-dependent branch needs an input that FORCES it at chosen tiles: one key per tile (3, 6, 9) whose score exceeds everything
+    before it by 1, 2, 3 x `jump` log2 units, for one query of a wave only, against an fp64 full-tensor reference.  (A deferred-max form —
+    keep the old max while growth stays below 2^8 — passed this test too but bought nothing on this kernel: 57.2 vs 56-58 us.)"""
+    from cosyvoice_amd import ops
+    torch.manual_seed(4)
+    dev, B, H, T = "cuda", 1, 2, 640
+    q = torch.randn(B, T, H * 64, device=dev) * 0.5
+    k = torch.randn(B, T, H * 64, device=dev) * 0.5
+    v = torch.randn(B, T, H * 64, device=dev)
+    scale = 0.125
+    # spikes: key j of tile (3, 6, 9) lines up with query rows 5, 37, 70 (different q-tiles / waves): score += jump / (scale * log2 e) per step
+    for n, (jt, qi) in enumerate(((3, 5), (6, 37), (9, 70))):
+        j = jt * 64 + 11
+        for h in range(H):
+            qv = q[0, qi, h * 64:(h + 1) * 64]
+            want = (n + 1) * jump / (scale * 1.4426950408889634) + 6.0 / scale
+            k[0, j, h * 64:(h + 1) * 64] = qv * (want / (qv @ qv))
+    q, k, v = q.to(dt), k.to(dt), v.to(dt)
+    vt = torch.zeros(B, H, 64, T, device=dev, dtype=dt)
+    vt[:] = v.view(B, T, H, 64).permute(0, 2, 3, 1)
+    out = torch.zeros(B, T, H * 64, device=dev, dtype=dt)
+    ops.attention(q, k, vt, out, B=B, H=H, Hkv=H, Tq=T, Tk=T, scale=scale, q_bs=T * H * 64, ldq=H * 64, k_bs=T * H * 64, ldk=H * 64,
+                  vt_ld=T, o_bs=T * H * 64, ldo=H * 64)
+    torch.cuda.synchronize()
+    f = lambda a: a.double().view(B, T, H, 64).permute(0, 2, 1, 3)
+    ref = _ref(f(q), f(k), f(v), scale).permute(0, 2, 1, 3).reshape(B, T, H * 64)
+    err = (out.double() - ref).abs().max().item()
+    assert torch.isfinite(out).all() and err < tol, err
