@@ -372,6 +372,8 @@ class CosyVoice2Model:
                 return out
             finally:
                 ctxs.put((ctx, own, pf))
+                with llm_state_lock:
+                    llm_state["running"] -= 1
 
         def hift_job(mel, mel_ready, t_job):
             """HiFT (+ D2H) of one equal-length batch on its own stream over the flow CUs: the vocoder of batch i fills the CUs the
@@ -394,6 +396,13 @@ class CosyVoice2Model:
         def flow_job(b, llm_fut, idx, ready, stream):
             toks = llm_fut.result()[idx]
             t_job = time.perf_counter()
+            with llm_state_lock:
+                # every decode job of the run has ended and none is left to submit: the decode CUs are idle for good, so the remaining
+                # flow + HiFT passes (the pipeline's drain: up to 2 x llm_merge batches) take all CUs, not only the last batch
+                if llm_state["running"] == 0 and llm_state["all_submitted"]:
+                    stream = flow_full
+            if est is not None:   # tile sizes of the row-block kernels (and the solver graph that bakes them in) follow the CUs of the stream
+                est.cu_budget = 0 if stream is flow_full else (32 - k) * 8
             n_t = len(toks[0])
             if self.overlap_hift and all(len(t) == n_t for t in toks):
                 with torch.no_grad(), torch.cuda.stream(stream):
@@ -438,6 +447,12 @@ class CosyVoice2Model:
         inflight = deque()
         first = True
         merge = max(1, int(getattr(self, "llm_merge", 1)))
+        llm_state_lock = threading.Lock()
+        llm_state = {"running": 0, "all_submitted": False}
+        # pipeline fill: the first decode jobs are small so that the flow stream gets its first batches early and is then fed without a
+        # gap while the job size grows to `merge` (1, 2, 2, 3, merge, ...: with 4 batches per job from the start the flow CUs idled ~0.2 s)
+        ramp = [int(v) for v in os.environ.get("CV_LLM_RAMP", "1,2,2,3").split(",") if v]
+        n_jobs = 0
         with ThreadPoolExecutor(max_workers=n_llm) as llm_pool, ThreadPoolExecutor(max_workers=1) as flow_pool, \
                 ThreadPoolExecutor(max_workers=1) as hift_pool:
             while nxt is not None or inflight:
@@ -445,7 +460,8 @@ class CosyVoice2Model:
                 while nxt is not None and len(inflight) < (n_llm + 2) * merge:
                     bs, rows = [], 0
                     # the very first job stays a single batch: the pipeline fills sooner
-                    while nxt is not None and len(bs) < (1 if first else merge) and rows + len(nxt["texts"]) <= self.llm.max_batch:
+                    job_batches = min(merge, ramp[n_jobs]) if n_jobs < len(ramp) else merge
+                    while nxt is not None and len(bs) < job_batches and rows + len(nxt["texts"]) <= self.llm.max_batch:
                         rows += len(nxt["texts"])
                         bs.append(nxt)
                         nxt = next(it, None)
@@ -454,6 +470,10 @@ class CosyVoice2Model:
                             b["on_start"]()   # e.g. the conditioning broadcast: same order on every rank, never from worker threads
                     ready = torch.cuda.Event()
                     ready.record(caller)
+                    n_jobs += 1
+                    with llm_state_lock:
+                        llm_state["running"] += 1
+                        llm_state["all_submitted"] = nxt is None
                     lf = llm_pool.submit(llm_job, bs, ready, first)
                     for i, b in enumerate(bs):
                         last = nxt is None and i == len(bs) - 1
