@@ -269,9 +269,7 @@ __global__ __launch_bounds__(256, ((TPW == 2 && TPR >= 32) ? 3 : 2)) void skinny
   const int m = (lane & 15) + 16 * mr;
   const bool live = m < p.M;   // (dead rows run the arithmetic on zeros and store nothing: the row sums below need every lane)
   if (p.mode == 2) {
-    if constexpr (TPW == 2) {
-      const int nb = tile0 * 16 + 4 * g;          // gate tile columns in packed order
-      const int hcol = (tile0 >> 1) * 16 + 4 * g;  // output column
+    if constexpr (TPW >= 2) {   // TPW / 2 (gate, up) tile pairs
       float rstd = 1.f;
       if constexpr (RS) {
         float rs_t = rs_sum[mr];
@@ -279,17 +277,22 @@ __global__ __launch_bounds__(256, ((TPW == 2 && TPR >= 32) ? 3 : 2)) void skinny
         rs_t += __shfl_xor(rs_t, 32, 64);
         rstd = rsqrtf(rs_t / (float)p.K + p.rs_eps);
       }
-      float h[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float gt = v[0][r] * rstd, up = v[1][r] * rstd;
-        if (p.bias) { gt += p.bias[nb + r]; up += p.bias[nb + 16 + r]; }
-        h[r] = act_silu(gt) * up;
+      for (int pr = 0; pr < TPW / 2; ++pr) {
+        const int nb = (tile0 + 2 * pr) * 16 + 4 * g;          // gate tile columns in packed order
+        const int hcol = ((tile0 + 2 * pr) >> 1) * 16 + 4 * g;  // output column
+        float h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float gt = v[2 * pr][r] * rstd, up = v[2 * pr + 1][r] * rstd;
+          if (p.bias) { gt += p.bias[nb + r]; up += p.bias[nb + 16 + r]; }
+          h[r] = act_silu(gt) * up;
+        }
+        uint2 u;
+        u.x = pack2<DT>(h[0], h[1]);
+        u.y = pack2<DT>(h[2], h[3]);
+        if (live) *(uint2*)((uint16_t*)p.out_act + (int64_t)m * p.ldoa + hcol) = u;
       }
-      uint2 u;
-      u.x = pack2<DT>(h[0], h[1]);
-      u.y = pack2<DT>(h[2], h[3]);
-      if (live) *(uint2*)((uint16_t*)p.out_act + (int64_t)m * p.ldoa + hcol) = u;
     }
     continue;
   }
@@ -1323,8 +1326,16 @@ extern "C" int cv_skinny_gemm(const cv_skinny_params* pp, void* stream) {
     const bool exact7 = per_wave == 7 && ((p.K >> 5) == 28 * p.ksplit);
     if (tpw == 2) {
       if (!p.rs_part) return CV_ERR_UNSUPPORTED;
+      // (two (gate, up) tile pairs per workgroup — skinny_kernel<DT, 4, 0, 16, 7, true, 2>, half the activation traffic — was measured at
+      // 19.9 vs 20.7 us on 64 CUs and 10.8 vs 10.4 us on all: at 240 VGPRs its 152 workgroups still need two rounds; not dispatched)
       if (exact7) { DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, 2, 0, 16, 7, true, 2>), grid, dim3(256), lds, st, p)); }
       else { DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, 2, 0, 16, 8, true, 2>), grid, dim3(256), lds, st, p)); }
+    } else if (per_wave > 8 && per_wave <= 10 && !(ntiles & 1)) {
+      // long-K form (the down projection): with two row groups the activation slice a workgroup reads (32 rows x its K range) is twice
+      // its weight tile, so two weight tiles share it (TPW = 2: half the workgroups, half the activation traffic)
+      dim3 grid2(ngroups / 2, p.ksplit);
+      const size_t lds2 = 2 * 4 * 2 * 64 * 4 * sizeof(float);
+      DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, 2, 0, 16, 10, false, 2>), grid2, dim3(256), lds2, st, p));
     } else if (exact7) { DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, 1, 0, 16, 7, false, 2>), grid, dim3(256), lds, st, p)); }
     else if (per_wave <= 8) { DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, 1, 0, 16, 8, false, 2>), grid, dim3(256), lds, st, p)); }
     else if (per_wave <= 12) { DISPATCH_16(p.dtype, hipLaunchKernelGGL((skinny_kernel<DT, 1, 0, 16, 12, false, 2>), grid, dim3(256), lds, st, p)); }
