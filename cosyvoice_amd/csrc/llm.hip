@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void pack_skinny_kernel(const uint16_t* W, uin
 // 8-utterance batches in one token loop) cost ONE weight stream.  Plain-row forms only (NORM == 0: beyond 8 rows the input norm is
 // its own launch); the split-norm partial sums are then pitched 16 * MR floats per part.
 template <int DT, int TPW, int NORM, int TPR, int U, bool RS = false, int MR = 1>   // RS: consumer half of a split RMSNorm (rs_part)
-__global__ __launch_bounds__(256, ((TPW == 2 && TPR >= 32) ? 3 : 2)) void skinny_kernel(const cv_skinny_params p) {
+__global__ __launch_bounds__(256, ((TPW == 2 && (TPR >= 32 || (MR == 2 && RS))) ? 3 : 2)) void skinny_kernel(const cv_skinny_params p) {
   static_assert(MR == 1 || NORM == 0, "row groups: plain activation rows only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float (*red)[TPW * MR][64][4] = (float (*)[TPW * MR][64][4])smem;   // [4][TPW * MR][64][4]
@@ -224,11 +224,13 @@ __global__ __launch_bounds__(256, ((TPW == 2 && TPR >= 32) ? 3 : 2)) void skinny
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) acc[t][mr] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  // SEQ_A (the gate/up form with two row groups): the second group's activation fragments are fetched only after the first group's
+  // MFMAs, into the same registers — one more L2 round trip per workgroup, but 140 instead of 196 VGPRs: three workgroups per CU, and the
+  // 304 workgroups of the launch take two rounds instead of three on the decode loops' 64 CUs.
+  constexpr bool SEQ_A = MR == 2 && TPW == 2 && RS;
   for (int ks = w0; ks < w1; ks += U) {
     if (ks != w0) load_w(ks);
-    uint4 a[MR][U];
-#pragma unroll
-    for (int mr = 0; mr < MR; ++mr)
+    auto load_a = [&](uint4 (&a)[U], int mr) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         // unconditional clamped load, masked to zero beyond the slice (the clamped weight fragment then contributes 0)
@@ -238,14 +240,31 @@ __global__ __launch_bounds__(256, ((TPW == 2 && TPR >= 32) ? 3 : 2)) void skinny
         if constexpr (NORM != 0) t = *(const uint4*)(aimg + ((kk * 64 + lane) << 4));
         else t = *(const uint4*)(Arow[mr] + kk * 32);
         const uint32_t msk = ok ? ((NORM != 0) ? 0xFFFFFFFFu : rowmask[mr]) : 0u;
-        a[mr][u] = make_uint4(t.x & msk, t.y & msk, t.z & msk, t.w & msk);
+        a[u] = make_uint4(t.x & msk, t.y & msk, t.z & msk, t.w & msk);
       }
+    };
+    if constexpr (SEQ_A) {
+      uint4 a[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+      for (int mr = 0; mr < MR; ++mr) {
+        load_a(a, mr);
 #pragma unroll
-      for (int t = 0; t < TPW; ++t)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) acc[t][mr] = mfma_block<DT>(w[t][u], a[mr][u], acc[t][mr]);
+          for (int t = 0; t < TPW; ++t) acc[t][mr] = mfma_block<DT>(w[t][u], a[u], acc[t][mr]);
+        __builtin_amdgcn_sched_barrier(0);   // keep the second group's loads behind the first group's MFMAs (register reuse)
+      }
+    } else {
+      uint4 a[MR][U];
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr) load_a(a[mr], mr);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr) acc[t][mr] = mfma_block<DT>(w[t][u], a[mr][u], acc[t][mr]);
+    }
   }
 #pragma unroll
   for (int t = 0; t < TPW; ++t)
