@@ -36,6 +36,7 @@ class GemmParams(C.Structure):
         ("q_cols", _i32), ("k_cols", _i32), ("q_scale", _f32),
         ("k_out", _vp), ("k_bs", _i64), ("ldk", _i32),
         ("vt_out", _vp), ("vt_heads", _i32), ("vt_ld", _i32),
+        ("x3_flags", _i32), ("reserved_x3", _i32),
     ]
 
 
@@ -186,7 +187,8 @@ class FlowSolverDesc(C.Structure):
 
 
 class HiftConv(C.Structure):
-    _fields_ = [("w", _vp), ("b", _vp), ("k", _i32), ("cin", _i32), ("cout", _i32), ("dilation", _i32), ("pad_left", _i32), ("stride", _i32)]
+    _fields_ = [("w", _vp), ("b", _vp), ("k", _i32), ("cin", _i32), ("cout", _i32), ("dilation", _i32), ("pad_left", _i32), ("stride", _i32),
+                ("x3_flags", _i32), ("reserved", _i32)]
 
 
 class HiftResunit(C.Structure):
@@ -202,7 +204,7 @@ class HiftPhase(C.Structure):
 
 
 class HiftStage(C.Structure):
-    _fields_ = [("phases", C.POINTER(HiftPhase)), ("up_b", _vp), ("u", _i32), ("up_cin", _i32),
+    _fields_ = [("phases", C.POINTER(HiftPhase)), ("up_b", _vp), ("u", _i32), ("up_cin", _i32), ("up_flags", _i32), ("reserved", _i32),
                 ("source_down", HiftConv), ("source_rb", HiftResblock), ("rbs", C.POINTER(HiftResblock)),
                 ("t_out", _i32), ("c", _i32),
                 ("x32", _vp), ("xa", C.POINTER(_vp)), ("r0", _vp), ("r1", _vp), ("ta", _vp), ("ra", _vp), ("acc0", _vp), ("acc1", _vp),
@@ -211,7 +213,7 @@ class HiftStage(C.Structure):
 
 class HiftDecodeDesc(C.Structure):
     _fields_ = [("dtype", _i32), ("gemm_dtype", _i32), ("B", _i32), ("T", _i32), ("S", _i32), ("n_stages", _i32), ("n_kernels", _i32),
-                ("stft_ld", _i32), ("hop", _i32), ("lrelu_slope", _f32), ("audio_limit", _f32),
+                ("stft_ld", _i32), ("hop", _i32), ("presplit", _i32), ("lrelu_slope", _f32), ("audio_limit", _f32),
                 ("conv_pre", HiftConv), ("conv_post", HiftConv), ("stages", C.POINTER(HiftStage)),
                 ("mel_cl", _vp), ("s", _vp), ("stft", _vp), ("a_pre", _vp), ("post", _vp), ("wav", _vp)]
 

@@ -253,7 +253,7 @@ class BigVGAN:
             t_out, c = ws["lens"][i], ws["chans"][i]
             up, x32 = self.ups[i], ws[f"x{i}"]
             cres = cond_res(i + 1, t_out) if cfg.cond_in_each_up_layer else None
-            for r, (wp, ntaps, cr) in enumerate(up.phases):   # ConvTranspose1d as `u` phase GEMMs (+ conds[i], :421-425)
+            for r, (wp, ntaps, cr, _) in enumerate(up.phases):   # ConvTranspose1d as `u` phase GEMMs (+ conds[i], :421-425)
                 ops.gemm(cur_a, wp, t_in, c, ntaps * up.cin, batch=B, a_bs=(cur_a.stride(0), 0), lda=cur_a.stride(1),
                          a_rows=t_in, cin=up.cin, tap_base=cr, tap_step=-1, bias=up.b,
                          res=(ws["conds"][i + 1] if cres is not None else None),

@@ -47,6 +47,22 @@ __device__ __forceinline__ void store_act4(void* base, int64_t idx, float a, flo
   }
 }
 
+// fp32 values in the PRE-SPLIT storage of the bf16x3 path: every aligned group of 8 values (32 bytes) holds [8 x bf16 hi | 8 x bf16 lo]
+// (hi = bf16(v), lo = bf16(v - hi): exactly what the consumer's LDS store would compute, computed once by the producer instead of
+// once per tap and per tile column by every consumer).  A lane holds 4 consecutive values (idx % 4 == 0): two 8-byte stores.
+__device__ __forceinline__ void store_split4(void* base, int64_t idx, float a, float b, float c, float d) {
+  const float f[4] = {a, b, c, d};
+  uint16_t h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    h[j] = Elem16<CV_BF16>::from_f32(f[j]);
+    l[j] = Elem16<CV_BF16>::from_f32(f[j] - Elem16<CV_BF16>::to_f32(h[j]));
+  }
+  char* g = (char*)base + (idx & ~(int64_t)7) * 4 + ((idx >> 2) & 1) * 8;   // group base + which half of the group this lane fills
+  *(uint2*)g = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+  *(uint2*)(g + 16) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+}
+
 template <int DT, int MT, int NT>
 __device__ __forceinline__ void gemm_epilogue(const cv_gemm_params& p, f32x4_t (&acc)[MT][NT], int m0, int n0, int wave_m, int wave_n,
                                               int lane, int z, int z0, int z1) {
@@ -108,10 +124,12 @@ __device__ __forceinline__ void gemm_epilogue(const cv_gemm_params& p, f32x4_t (
         const float v2 = (acc[i][j][2] + b4[j].z + r4[j].z) * p.out_scale;
         const float v3 = (acc[i][j][3] + b4[j].w + r4[j].w) * p.out_scale;
         if (o32) *(float4*)(o32 + (int64_t)orow[i] * p.ldo32 + nbj[j]) = make_float4(v0, v1, v2, v3);
-        if (oact)
-          store_act4<DT>(oact, (int64_t)orow[i] * p.ldoa + nbj[j], apply_act(p.act, v0, ap4[j].x, p.act_slope),
-                         apply_act(p.act, v1, ap4[j].y, p.act_slope), apply_act(p.act, v2, ap4[j].z, p.act_slope),
-                         apply_act(p.act, v3, ap4[j].w, p.act_slope));
+        if (oact) {
+          const float a0 = apply_act(p.act, v0, ap4[j].x, p.act_slope), a1 = apply_act(p.act, v1, ap4[j].y, p.act_slope);
+          const float a2 = apply_act(p.act, v2, ap4[j].z, p.act_slope), a3 = apply_act(p.act, v3, ap4[j].w, p.act_slope);
+          if (DT == CV_F32 && (p.x3_flags & 4)) store_split4(oact, (int64_t)orow[i] * p.ldoa + nbj[j], a0, a1, a2, a3);
+          else store_act4<DT>(oact, (int64_t)orow[i] * p.ldoa + nbj[j], a0, a1, a2, a3);
+        }
       }
     }
     return;
@@ -187,9 +205,14 @@ __device__ __forceinline__ void gemm_epilogue(const cv_gemm_params& p, f32x4_t (
 // The split happens when a tile is written to LDS: the 128-byte row that held 32 floats holds 32 hi (chunks 0-3) + 32 lo
 // (chunks 4-7) bf16 values, i.e. exactly the two fragment reads of the 16-bit path, and 3 MFMA 16x16x32 replace the
 // 8 exact-f32 16x16x4 per K tile (the f32 MFMA peak is 1/16 of bf16: the HiFT / BigVGAN convs were MFMA-bound on it).
-template <int DT, int BM, int BN, int WM = 2, int WN = 2, bool X3 = false>
+// PS (with X3): both operands arrive PRE-SPLIT (store_split4's 8-value group format: activations written so by the producing launch's
+// epilogue, weights converted once on the host) — the LDS store is then one 16-byte copy per chunk, conflict-free like the 16-bit path
+// (the split form's 8-byte hi / lo stores showed 33 % LDS bank-conflict cycles, profiles/r01_k).  Without it the split costs ~150 VALU
+// instructions per thread per K tile against 24 MFMAs per wave (the HiFT convs re-split every activation once per tap and tile column).
+template <int DT, int BM, int BN, int WM = 2, int WN = 2, bool X3 = false, bool PS = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const cv_gemm_params p) {
   static_assert(!X3 || DT == CV_F32, "the bf16x3 split is a mode of the fp32 path");
+  static_assert(!PS || X3, "pre-split operands belong to the bf16x3 path");
   constexpr int NTHR = 64 * WM * WN;
   constexpr int ES = ElemSize<DT>::value;
   constexpr int CH = 16 / ES;    // elements per 16-byte chunk
@@ -242,7 +265,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const cv_gemm_params
     const int c = i * NTHR + tid;
     const int row = c >> 3, kc = c & 7;  // 8 consecutive lanes = one 128-byte line of a row
     const int m = m0 + row;
-    a_lds[i] = X3 ? lds_chunk_off(row, kc >> 1) + ((kc & 1) << 3) : lds_chunk_off(row, kc);   // X3: hi half-chunk
+    a_lds[i] = PS ? lds_chunk_off(row, (kc >> 1) + 4 * (kc & 1))                              // PS: whole hi / lo chunk
+               : (X3 ? lds_chunk_off(row, kc >> 1) + ((kc & 1) << 3) : lds_chunk_off(row, kc));   // X3: hi half-chunk
     a_lds2[i] = lds_chunk_off(row, 4 + (kc >> 1)) + ((kc & 1) << 3);                            //     lo half-chunk
     a_m_ok[i] = m < p.M;
     a_rowbase[i] = m * p.a_row_stride + p.tap_base;
@@ -261,7 +285,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const cv_gemm_params
     const int c = i * NTHR + tid;
     const int row = c >> 3, kc = c & 7;
     const int n = n0 + row;
-    b_lds[i] = BM * 128 + (X3 ? lds_chunk_off(row, kc >> 1) + ((kc & 1) << 3) : lds_chunk_off(row, kc));
+    b_lds[i] = BM * 128 + (PS ? lds_chunk_off(row, (kc >> 1) + 4 * (kc & 1))
+                              : (X3 ? lds_chunk_off(row, kc >> 1) + ((kc & 1) << 3) : lds_chunk_off(row, kc)));
     b_lds2[i] = BM * 128 + lds_chunk_off(row, 4 + (kc >> 1)) + ((kc & 1) << 3);
     b_ok[i] = n < p.N;
     b_k[i] = kc * CH;
@@ -321,7 +346,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const cv_gemm_params
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       const uint32_t mk = ((amask >> i) & 1u) ? 0xFFFFFFFFu : 0u;
-      if constexpr (X3) {
+      if constexpr (PS) {   // the 16-byte chunk is 8 hi (even chunk) or 8 lo (odd chunk) values: one conflict-free 16-byte store
+        *(uint4*)(smem + a_lds[i]) = make_uint4(ra[i].x & mk, ra[i].y & mk, ra[i].z & mk, ra[i].w & mk);
+      } else if constexpr (X3) {
         uint2 hi, lo;
         split4(ra[i], mk, hi, lo);
         *(uint2*)(smem + a_lds[i]) = hi;
@@ -333,7 +360,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const cv_gemm_params
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
       const uint32_t mk = ((bmask >> i) & 1u) ? 0xFFFFFFFFu : 0u;
-      if constexpr (X3) {
+      if constexpr (PS) {
+        *(uint4*)(smem + b_lds[i]) = make_uint4(rb[i].x & mk, rb[i].y & mk, rb[i].z & mk, rb[i].w & mk);
+      } else if constexpr (X3) {
         uint2 hi, lo;
         split4(rb[i], mk, hi, lo);
         *(uint2*)(smem + b_lds[i]) = hi;
@@ -402,12 +431,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const cv_gemm_params
   gemm_epilogue<DT, MT, NT>(p, acc, m0, n0, wave_m, wave_n, lane, z, z0, z1);
 }
 
-template <int DT, int BM, int BN, int WM = 2, int WN = 2, bool X3 = false>
+template <int DT, int BM, int BN, int WM = 2, int WN = 2, bool X3 = false, bool PS = false>
 int launch(const cv_gemm_params& p, hipStream_t st) {
   const int mt = (p.M + BM - 1) / BM, nt = (p.N + BN - 1) / BN;
   dim3 grid(mt * nt, 1, p.batch);
   const size_t lds = (BM + BN) * 128;
-  hipLaunchKernelGGL((gemm_kernel<DT, BM, BN, WM, WN, X3>), grid, dim3(64 * WM * WN), lds, st, p);
+  hipLaunchKernelGGL((gemm_kernel<DT, BM, BN, WM, WN, X3, PS>), grid, dim3(64 * WM * WN), lds, st, p);
   CV_CHECK_LAUNCH();
   return CV_OK;
 }
@@ -570,7 +599,13 @@ static int g_tile_override = -2;
 // fp32 tensors, bf16x3 products: the two register-staged tiles only
 int dispatch_x3(const cv_gemm_params& p, hipStream_t st) {
   const long long t12864 = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * p.batch;
-  if (p.act == CV_ACT_SWIGLU || (p.K > 512 && t12864 >= 768)) return launch<CV_F32, 128, 64, 2, 2, true>(p, st);
+  const bool big = p.act == CV_ACT_SWIGLU || (p.K > 512 && t12864 >= 768);
+  if ((p.x3_flags & 3) == 3) {   // both operands pre-split
+    if (big) return launch<CV_F32, 128, 64, 2, 2, true, true>(p, st);
+    return launch<CV_F32, 64, 64, 2, 2, true, true>(p, st);
+  }
+  if (p.x3_flags & 3) return CV_ERR_UNSUPPORTED;   // one operand pre-split, the other not
+  if (big) return launch<CV_F32, 128, 64, 2, 2, true>(p, st);
   return launch<CV_F32, 64, 64, 2, 2, true>(p, st);
 }
 
@@ -634,6 +669,9 @@ extern "C" int cv_gemm(const cv_gemm_params* pp, void* stream) {
     if (p.out_f32 && ((p.ldo32 & 3) || ((uintptr_t)p.out_f32 & 15) || (p.o32_bs0 & 3) || (p.o32_bs1 & 3))) return CV_ERR_ARG;
     if (p.out_act && ((p.ldoa & 3) || ((uintptr_t)p.out_act & 15) || (p.oa_bs0 & 3) || (p.oa_bs1 & 3))) return CV_ERR_ARG;
   }
+  if (p.x3_flags && (!x3 || (p.x3_flags & ~7))) return CV_ERR_ARG;          // pre-split storage belongs to CV_F32X3 launches
+  if ((p.x3_flags & 4) && (!p.out_act || (p.N & 7) || (p.ldoa & 7) || p.act == CV_ACT_SWIGLU || p.out_mode != CV_OUT_ROWMAJOR)) return CV_ERR_ARG;
+  if ((p.x3_flags & 3) && ((p.K & 7) || (p.cin & 7) || (p.lda & 7) || (p.ldw & 7))) return CV_ERR_ARG;   // 8-value groups
   hipStream_t st = (hipStream_t)stream;
   if (x3) return dispatch_x3(p, st);
   switch (p.dtype) {

@@ -58,7 +58,18 @@ __global__ __launch_bounds__(256) void snake_multi_kernel(const float* x, int64_
     for (int k = 0; k < n; ++k) {
       const float4 al = *(const float4*)(a.alpha[k] + col);
       const float o0 = act_snake(v.x, al.x), o1 = act_snake(v.y, al.y), o2 = act_snake(v.z, al.z), o3 = act_snake(v.w, al.w);
-      if constexpr (DT == CV_F32) {
+      if constexpr (DT == CV_F32X3) {   // pre-split storage of the bf16x3 convs (cv_gemm_params.x3_flags)
+        const float f[4] = {o0, o1, o2, o3};
+        uint16_t h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          h[j] = Elem16<CV_BF16>::from_f32(f[j]);
+          l[j] = Elem16<CV_BF16>::from_f32(f[j] - Elem16<CV_BF16>::to_f32(h[j]));
+        }
+        char* g = (char*)a.out[k] + (row * ldo + (col & ~7)) * 4 + ((col >> 2) & 1) * 8;   // 8-value group [8 hi | 8 lo], this lane's half
+        *(uint2*)g = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+        *(uint2*)(g + 16) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+      } else if constexpr (DT == CV_F32) {
         *(float4*)((float*)a.out[k] + row * ldo + col) = make_float4(o0, o1, o2, o3);
       } else {
         uint2 u;
@@ -226,7 +237,8 @@ extern "C" int cv_snake_multi(const float* x, int32_t rows, int32_t C, int32_t l
   for (int i = 0; i < n; ++i) { a.alpha[i] = alpha[i]; a.out[i] = out[i]; if (!alpha[i] || !out[i]) return CV_ERR_ARG; }
   const int64_t n4 = (int64_t)rows * (C >> 2);
   const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-  DISPATCH_DT(dtype, hipLaunchKernelGGL(snake_multi_kernel<DT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n4, C, ldx, n, ldo, a));
+  if (dtype == CV_F32X3) hipLaunchKernelGGL(snake_multi_kernel<CV_F32X3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n4, C, ldx, n, ldo, a);
+  else DISPATCH_DT(dtype, hipLaunchKernelGGL(snake_multi_kernel<DT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n4, C, ldx, n, ldo, a));
   CV_CHECK_LAUNCH();
   return CV_OK;
 }

@@ -274,6 +274,7 @@ int hconv(const cv_hift_decode_desc& d, const cv_hift_conv& c, const void* x, in
   if (e.out_f32) { const int ld = e.ldo32 ? e.ldo32 : c.cout; p.out_f32 = e.out_f32; p.o32_bs0 = (int64_t)T_out * ld; p.ldo32 = ld; }
   if (e.out_act) { p.out_act = e.out_act; p.oa_bs0 = (int64_t)T_out * c.cout; p.ldoa = c.cout; }
   p.out_row_stride = 1;
+  p.x3_flags = e.out_act ? c.x3_flags : (c.x3_flags & ~4);
   return cv_gemm(&p, st);
 }
 
@@ -329,6 +330,7 @@ int enqueue_hift_decode(const cv_hift_decode_desc& d, hipStream_t st) {
       p.res = sg.si1; p.res_bs0 = (int64_t)t_out * c; p.ldres = c; p.out_scale = 1.0f;
       p.out_f32 = sg.x32; p.o32_bs0 = (int64_t)t_out * c; p.ldo32 = c;
       p.out_row_stride = sg.u; p.out_row_off = row_off; p.out_rows = t_out;
+      p.x3_flags = sg.up_flags;
       return cv_gemm(&p, st);
     };
     const int off = last ? 1 : 0;
@@ -340,7 +342,7 @@ int enqueue_hift_decode(const cv_hift_decode_desc& d, hipStream_t st) {
     {
       const float* alphas[8]; void* outs[8];
       for (int j = 0; j < d.n_kernels; ++j) { alphas[j] = sg.rbs[j].units[0].a1; outs[j] = sg.xa[j]; }
-      if (int rc = cv_snake_multi(sg.x32, B * t_out, c, c, d.n_kernels, alphas, outs, c, d.dtype, st)) return rc;
+      if (int rc = cv_snake_multi(sg.x32, B * t_out, c, c, d.n_kernels, alphas, outs, c, d.presplit ? (int)CV_F32X3 : d.dtype, st)) return rc;
     }
     const float slope = last ? 0.01f : d.lrelu_slope;   // F.leaky_relu default after the loop (generator.py:374)
     for (int j = 0; j < d.n_kernels; ++j) {

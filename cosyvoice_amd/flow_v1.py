@@ -109,7 +109,7 @@ class ConditionalDecoderV1(ConditionalDecoder):
         # up 0 @T/2 on [x | skip1]; Upsample1D = ConvTranspose1d(4, 2, 1) -> cat_hi[:, :, :C] (frame 2*Td - 1 >= T is dropped)
         self._stage(self.blocks[nb - 2], lo, R, lo["cat"], 2 * C, 2 * C, ta(nb - 2), lo["d"], C)
         up = self.up0
-        for r, (wp, ntaps, cr) in enumerate(up.phases):
+        for r, (wp, ntaps, cr, _) in enumerate(up.phases):
             ops.gemm(lo["d"], wp, Td, C, ntaps * C, batch=R, a_bs=(Td * C, 0), lda=C, a_rows=Td, cin=C, tap_base=cr, tap_step=-1,
                      bias=up.b, out_act=ws["cat"], oa_bs=(T * 2 * C, 0), ldoa=2 * C, out_row_stride=2, out_row_off=r, out_rows=T)
         # up 1 @T on [x | skip0]; Conv1d(k3, pad 1); final Block1D; final_proj

@@ -26,6 +26,18 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
+def _presplit(w32: torch.Tensor) -> torch.Tensor:
+    """fp32 (rows, K) with K % 8 == 0 -> the pre-split storage of the bf16x3 GEMM (cv_gemm_params.x3_flags): every 8 values
+    become [8 x bf16 hi | 8 x bf16 lo] in the same 32 bytes, hi = bf16(w), lo = bf16(w - hi).  Returned as int16 (rows, 2K)."""
+    w32 = w32.to(torch.float32).cpu()
+    hi = w32.to(torch.bfloat16)
+    lo = (w32 - hi.to(torch.float32)).to(torch.bfloat16)
+    rows, K = w32.shape
+    assert K % 8 == 0
+    out = torch.cat([hi.view(rows, K // 8, 8), lo.view(rows, K // 8, 8)], dim=2)   # (rows, K/8, 16) bf16
+    return out.contiguous().view(torch.int16).reshape(rows, 2 * K)
+
+
 class _Conv:
     """Packed Conv1d: W' [Cout][tap*Cin_pad + ci]."""
 
@@ -36,6 +48,7 @@ class _Conv:
         wp = torch.zeros(cout, k, self.cin_pad, dtype=torch.float32)
         wp[:, :, :cin] = w.permute(0, 2, 1)
         self.w = wp.reshape(cout, k * self.cin_pad).to(device=device, dtype=dtype).contiguous()
+        self.w_s = _presplit(wp.reshape(cout, k * self.cin_pad)).to(device) if (dtype == torch.float32 and self.cin_pad % 8 == 0) else None
         self.b = b.to(device=device, dtype=torch.float32).contiguous() if b is not None else None
         self.k, self.cout, self.dilation, self.pad_left, self.stride = k, cout, dilation, pad_left, stride
 
@@ -53,7 +66,9 @@ class _ConvT:
             j0, c = (r + p) % u, (r + p) // u
             taps = list(range(j0, k, u))
             wp = torch.stack([w[:, :, j].t() for j in taps], dim=1)  # (cout, ntaps, cin)
-            self.phases.append((wp.reshape(cout, len(taps) * cin).to(device=device, dtype=dtype).contiguous(), len(taps), c))
+            w2 = wp.reshape(cout, len(taps) * cin)
+            self.phases.append((w2.to(device=device, dtype=dtype).contiguous(), len(taps), c,
+                                _presplit(w2).to(device) if (dtype == torch.float32 and cin % 8 == 0) else None))
 
 
 class HiFTGenerator:
@@ -71,6 +86,15 @@ class HiFTGenerator:
         self._loaded = False
         self._ws: Dict[tuple, dict] = {}
         self.use_stage_abi = os.environ.get("CV_HIFT_STAGE_ABI", "1") != "0"   # decode composed by cv_hift_decode_enqueue
+
+    @property
+    def presplit(self):
+        """fp32 tensors with bf16x3 products: activations between the decoder's convs and the weights are kept PRE-SPLIT (hi / lo bf16
+        planes per 4 values, cv_gemm_params.x3_flags) — the producer's epilogue splits once what every consuming conv would otherwise
+        split once per tap and tile column.  Bit-identical to the plain bf16x3 launches (CV_HIFT_PRESPLIT=0), tested."""
+        chans = [self.cfg.base_channels // 2 ** i for i in range(self.num_upsamples + 1)]   # 8-value groups along the channel axis
+        return (self.dtype == torch.float32 and self.f32_products == "bf16x3" and all(c % 8 == 0 for c in chans)
+                and os.environ.get("CV_HIFT_PRESPLIT", "1") != "0")
 
     # -- torch.nn.Module-like surface used by cli/model.py:72-81
     def to(self, *a, **k):
@@ -169,8 +193,13 @@ class HiFTGenerator:
         return ws
 
     # ------------------------------------------------------------------ building blocks
-    def _conv(self, c: _Conv, x, T_out=None, **kw):
-        ops.conv1d_cl(x, c.w, c.k, dilation=c.dilation, pad_left=c.pad_left, stride=c.stride, T_out=T_out, bias=c.b, **kw)
+    def _conv(self, c: _Conv, x, T_out=None, flags=0, **kw):
+        """``flags`` = cv_gemm_params.x3_flags (decoder convs under ``presplit``): 3 = operands pre-split (the packed weights are then
+        c.w_s), 4 = write out_act pre-split."""
+        w = c.w_s.view(torch.float32) if (flags & 2) else c.w
+        if kw.get("out_act") is None:
+            flags &= ~4
+        ops.conv1d_cl(x, w, c.k, dilation=c.dilation, pad_left=c.pad_left, stride=c.stride, T_out=T_out, bias=c.b, x3_flags=flags, **kw)
 
     def _resblock(self, rb, x32, xa, ws, i, final):
         """x32: fp32 block input; xa: snake_{a1[0]}(x32) in dtype.  ``final`` = kwargs of the last conv2's epilogue
@@ -178,14 +207,15 @@ class HiFTGenerator:
         r, ta, ra = ws[f"r{i}"], ws[f"ta{i}"], ws[f"ra{i}"]
         cur32, cur_a = x32, xa
         n = len(rb)
+        fl = 7 if self.presplit else 0
         for j, blk in enumerate(rb):
-            self._conv(blk["c1"], cur_a, act=ops.ACT_SNAKE, act_param=blk["a2"], out_act=ta)
+            self._conv(blk["c1"], cur_a, flags=fl, act=ops.ACT_SNAKE, act_param=blk["a2"], out_act=ta)
             if j < n - 1:
                 nxt = r[j & 1]
-                self._conv(blk["c2"], ta, res=cur32, out_f32=nxt, act=ops.ACT_SNAKE, act_param=rb[j + 1]["a1"], out_act=ra)
+                self._conv(blk["c2"], ta, flags=fl, res=cur32, out_f32=nxt, act=ops.ACT_SNAKE, act_param=rb[j + 1]["a1"], out_act=ra)
                 cur32, cur_a = nxt, ra
             else:
-                self._conv(blk["c2"], ta, res=cur32, **final)
+                self._conv(blk["c2"], ta, flags=fl, res=cur32, **final)
 
     # ------------------------------------------------------------------ public API
     @torch.no_grad()
@@ -225,9 +255,10 @@ class HiFTGenerator:
             # instead of ~100); _decode_cl_impl stays as the cross-check of the C composition (tests/test_hift_gpu.py)
             from . import _lib as L
             import ctypes as C
-            ent = ws.get("_desc")
+            key = ("_desc", self.presplit)
+            ent = ws.get(key)
             if ent is None:
-                ent = ws["_desc"] = self.decode_desc(ws, B, T)
+                ent = ws[key] = self.decode_desc(ws, B, T)
             desc = ent[0]
             desc.gemm_dtype = L.CV_F32X3 if (self.dtype == torch.float32 and self.f32_products == "bf16x3") else L.TORCH_DT[self.dtype]
             desc.s = s2.data_ptr()
@@ -244,10 +275,15 @@ class HiFTGenerator:
         cfg = self.cfg
         keep = []
 
-        def conv(c, cin):
+        ps = self.presplit
+        fl_in, fl = (4 if ps else 0), (7 if ps else 0)
+
+        def conv(c, cin, flags=None):
+            flags = fl if flags is None else flags
             h = L.HiftConv()
-            h.w, h.b = c.w.data_ptr(), (c.b.data_ptr() if c.b is not None else None)
+            h.w, h.b = (c.w_s if (flags & 2) else c.w).data_ptr(), (c.b.data_ptr() if c.b is not None else None)
             h.k, h.cin, h.cout, h.dilation, h.pad_left, h.stride = c.k, cin, c.cout, c.dilation, c.pad_left, c.stride
+            h.x3_flags = flags
             return h
 
         def resblock(rb, ch):
@@ -264,7 +300,8 @@ class HiFTGenerator:
         d.dtype, d.B, d.T, d.S = L.TORCH_DT[self.dtype], B, T, T * cfg.total_upsample
         d.n_stages, d.n_kernels, d.stft_ld, d.hop = self.num_upsamples, self.num_kernels, self._stft_ld, cfg.hop_len
         d.lrelu_slope, d.audio_limit = cfg.lrelu_slope, cfg.audio_limit
-        d.conv_pre = conv(self.conv_pre, ws["mel_cl"].shape[2])
+        d.presplit = int(ps)
+        d.conv_pre = conv(self.conv_pre, ws["mel_cl"].shape[2], fl_in)
         stages = (L.HiftStage * self.num_upsamples)()
         keep.append(stages)
         nk = self.num_kernels
@@ -273,10 +310,10 @@ class HiFTGenerator:
             t_out, c = ws["lens"][i], ws["chans"][i]
             ph = (L.HiftPhase * up.u)()
             keep.append(ph)
-            for r, (wp, ntaps, cr) in enumerate(up.phases):
-                ph[r].w, ph[r].ntaps, ph[r].tap_base = wp.data_ptr(), ntaps, cr
-            g.phases, g.up_b, g.u, g.up_cin = ph, up.b.data_ptr(), up.u, up.cin
-            g.source_down = conv(self.source_downs[i], self._stft_ld)
+            for r, (wp, ntaps, cr, wps) in enumerate(up.phases):
+                ph[r].w, ph[r].ntaps, ph[r].tap_base = (wps if ps else wp).data_ptr(), ntaps, cr
+            g.phases, g.up_b, g.u, g.up_cin, g.up_flags = ph, up.b.data_ptr(), up.u, up.cin, (3 if ps else 0)
+            g.source_down = conv(self.source_downs[i], self._stft_ld, fl_in)
             g.source_rb = resblock(self.source_resblocks[i], c)
             rbs = (L.HiftResblock * nk)(*[resblock(rb, c) for rb in self.resblocks[i * nk:(i + 1) * nk]])
             xa = (C.c_void_p * nk)(*[t.data_ptr() for t in ws[f"xa{i}"]])
@@ -295,7 +332,9 @@ class HiFTGenerator:
     def _decode_cl_impl(self, ws, B, T, s2):
         cfg = self.cfg
         ops.stft16(s2, ws["stft"])
-        self._conv(self.conv_pre, ws["mel_cl"], act=ops.ACT_LEAKY, act_slope=cfg.lrelu_slope, out_act=ws["a_pre"])
+        ps = self.presplit
+        fl_in, fl = (4 if ps else 0), (7 if ps else 0)   # first convs read plain fp32 (mel, STFT) and write pre-split activations
+        self._conv(self.conv_pre, ws["mel_cl"], flags=fl_in, act=ops.ACT_LEAKY, act_slope=cfg.lrelu_slope, out_act=ws["a_pre"])
         cur_a = ws["a_pre"]
         t_in = T
         nk = self.num_kernels
@@ -306,28 +345,29 @@ class HiFTGenerator:
             sd_, srb = self.source_downs[i], self.source_resblocks[i]
             si0, si1 = ws[f"si{i}"]
             xa_src = ws[f"xa{i}"][0]  # free here: the main resblocks have not started
-            self._conv(sd_, ws["stft"], T_out=t_out, out_f32=si0, act=ops.ACT_SNAKE, act_param=srb[0]["a1"], out_act=xa_src)
+            self._conv(sd_, ws["stft"], T_out=t_out, flags=fl_in, out_f32=si0, act=ops.ACT_SNAKE, act_param=srb[0]["a1"], out_act=xa_src)
             self._resblock(srb, si0, xa_src, ws, i, dict(out_f32=si1))
             # ups[i] (+ reflect pad on the last stage) + source fusion: x = ups(x) + si  (generator.py:355-364)
             up = self.ups[i]
             x32 = ws[f"x{i}"]
             off = 1 if last else 0
-            for r, (wp, ntaps, cr) in enumerate(up.phases):
-                ops.gemm(cur_a, wp, t_in, c, ntaps * up.cin, batch=B, a_bs=(cur_a.stride(0), 0), lda=cur_a.stride(1),
+            upf = 3 if ps else 0
+            for r, (wp, ntaps, cr, wps) in enumerate(up.phases):
+                ops.gemm(cur_a, wps.view(torch.float32) if ps else wp, t_in, c, ntaps * up.cin, batch=B, a_bs=(cur_a.stride(0), 0), lda=cur_a.stride(1),
                          a_rows=t_in, cin=up.cin, tap_base=cr, tap_step=-1, bias=up.b, res=si1,
                          res_bs=(si1.stride(0), 0), ldres=c, out_f32=x32, o32_bs=(x32.stride(0), 0), ldo32=c,
-                         out_row_stride=up.u, out_row_off=r + off, out_rows=t_out)
+                         out_row_stride=up.u, out_row_off=r + off, out_rows=t_out, x3_flags=upf, ldw=ntaps * up.cin)
             if last:
                 # ReflectionPad1d((1,0)): padded[0] = ups_out[1] = phase r=1, q=0
-                wp, ntaps, cr = up.phases[1]
-                ops.gemm(cur_a, wp, 1, c, ntaps * up.cin, batch=B, a_bs=(cur_a.stride(0), 0), lda=cur_a.stride(1),
+                wp, ntaps, cr, wps = up.phases[1]
+                ops.gemm(cur_a, wps.view(torch.float32) if ps else wp, 1, c, ntaps * up.cin, batch=B, a_bs=(cur_a.stride(0), 0), lda=cur_a.stride(1),
                          a_rows=t_in, cin=up.cin, tap_base=cr, tap_step=-1, bias=up.b, res=si1,
                          res_bs=(si1.stride(0), 0), ldres=c, out_f32=x32, o32_bs=(x32.stride(0), 0), ldo32=c,
-                         out_row_stride=up.u, out_row_off=0, out_rows=t_out)
+                         out_row_stride=up.u, out_row_off=0, out_rows=t_out, x3_flags=upf, ldw=ntaps * up.cin)
             # parallel ResBlocks, mean over kernels (generator.py:366-372)
             rbs = self.resblocks[i * nk:(i + 1) * nk]
             xas = ws[f"xa{i}"]
-            ops.snake_multi(x32.view(B * t_out, c), [rb[0]["a1"] for rb in rbs], [a.view(B * t_out, c) for a in xas])
+            ops.snake_multi(x32.view(B * t_out, c), [rb[0]["a1"] for rb in rbs], [a.view(B * t_out, c) for a in xas], split=ps)
             acc = ws[f"acc{i}"]
             slope = 0.01 if last else cfg.lrelu_slope  # F.leaky_relu default after the loop (generator.py:374)
             for j, rb in enumerate(rbs):
@@ -342,7 +382,7 @@ class HiFTGenerator:
                 self._resblock(rb, x32, xas[j], ws, i, fin)
             cur_a = ws[f"out{i}"]
             t_in = t_out
-        self._conv(self.conv_post, cur_a, out_f32=ws["post"])
+        self._conv(self.conv_post, cur_a, flags=fl, out_f32=ws["post"])
         ops.istft16(ws["post"], ws["wav"], cfg.audio_limit)
         return ws["wav"]
 

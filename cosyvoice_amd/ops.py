@@ -95,7 +95,7 @@ def _issue(name, p):
 def gemm(A, W, M, N, K, *, dtype=None, batch=1, batch_inner=0, a_bs=(0, 0), lda=None, a_rows=0, cin=0,
          a_row_stride=1, tap_base=0, tap_step=0, w_bs=(0, 0), ldw=None, bias=None, res=None, res_bs=(0, 0), ldres=0,
          res2=None, ldres2=0, out_scale=1.0, act=ACT_NONE, act_param=None, act_slope=0.0, out_f32=None, o32_bs=(0, 0),
-         ldo32=0, out_act=None, oa_bs=(0, 0), ldoa=0, out_row_stride=1, out_row_off=0, out_rows=0, qkv=None):
+         ldo32=0, out_act=None, oa_bs=(0, 0), ldoa=0, out_row_stride=1, out_row_off=0, out_rows=0, qkv=None, x3_flags=0):
     _req_cuda(A, W, bias, res, res2, out_f32, out_act)
     p = L.GemmParams()
     p.dtype = L.TORCH_DT[A.dtype] if dtype is None else dtype
@@ -112,6 +112,7 @@ def gemm(A, W, M, N, K, *, dtype=None, batch=1, batch_inner=0, a_bs=(0, 0), lda=
     p.out_f32, p.o32_bs0, p.o32_bs1, p.ldo32 = L.ptr(out_f32), o32_bs[0], o32_bs[1], ldo32
     p.out_act, p.oa_bs0, p.oa_bs1, p.ldoa = L.ptr(out_act), oa_bs[0], oa_bs[1], ldoa
     p.out_row_stride, p.out_row_off, p.out_rows = out_row_stride, out_row_off, out_rows
+    p.x3_flags = x3_flags if p.dtype == L.CV_F32X3 else 0   # pre-split operand / output storage of the bf16x3 path (cv_gemm_params.x3_flags)
     if qkv is not None:
         p.out_mode = OUT_QKV
         p.q_cols, p.k_cols, p.q_scale = qkv["q_cols"], qkv["k_cols"], qkv.get("q_scale", 1.0)
@@ -217,14 +218,15 @@ def to_channels_first(x, out, Cc=None):
                                          L.stream_ptr()), "cv_to_channels_first")
 
 
-def snake_multi(x2d, alphas, outs):
-    """x2d (rows, C) fp32; alphas: list of (C,) fp32; outs: list of (rows, C) tensors of one dtype."""
+def snake_multi(x2d, alphas, outs, split=False):
+    """x2d (rows, C) fp32; alphas: list of (C,) fp32; outs: list of (rows, C) tensors of one dtype.  ``split`` (fp32 outs): write the
+    pre-split chunk format of the bf16x3 convs ([4 x bf16 hi | 4 x bf16 lo] per 4 values)."""
     _req_cuda(x2d, *alphas, *outs)
     n = len(alphas)
     a = (C.c_void_p * n)(*[t.data_ptr() for t in alphas])
     o = (C.c_void_p * n)(*[t.data_ptr() for t in outs])
     L.check(L.lib().cv_snake_multi(C.c_void_p(x2d.data_ptr()), x2d.shape[0], x2d.shape[1], x2d.stride(0), n, a, o,
-                                   outs[0].stride(0), L.TORCH_DT[outs[0].dtype], L.stream_ptr()), "cv_snake_multi")
+                                   outs[0].stride(0), L.CV_F32X3 if split else L.TORCH_DT[outs[0].dtype], L.stream_ptr()), "cv_snake_multi")
 
 
 def stft16(s, out):

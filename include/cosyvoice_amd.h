@@ -66,6 +66,12 @@ typedef struct cv_gemm_params {
   int32_t q_cols, k_cols; float q_scale;
   void* k_out; int64_t k_bs; int32_t ldk;
   void* vt_out; int32_t vt_heads, vt_ld;
+  /* CV_F32X3 only — PRE-SPLIT storage of fp32 tensors: every aligned group of 8 values (32 bytes) holds [8 x bf16 hi | 8 x bf16 lo]
+   * with hi = bf16(v), lo = bf16(v - hi), i.e. what the bf16x3 kernel would otherwise compute each time it stages the values
+   * (row lengths / K / cin / leading dimensions % 8 == 0).
+   * bit 0: A is pre-split; bit 1: W is pre-split (both or neither); bit 2: out_act is WRITTEN pre-split (row-major, N % 8 == 0).
+   * Results are bit-identical to the plain CV_F32X3 launch. */
+  int32_t x3_flags; int32_t reserved_x3;
 } cv_gemm_params;
 int cv_gemm(const cv_gemm_params* p, void* stream);
 
@@ -204,7 +210,8 @@ int cv_to_channels_last(const float* x, void* out, int32_t dtype, int32_t B, int
 /* x [B][T][ldx] fp32 -> out [B][C][T] fp32 */
 int cv_to_channels_first(const float* x, float* out, int32_t B, int32_t C, int32_t T, int32_t ldx, void* stream);
 /* Snake x + sin^2(a x)/(a+1e-9) (transformer/activation.py:73-84) of x [rows][C] fp32 with up to 4 alpha vectors,
- * one `dtype` output per alpha: the first activation of the parallel ResBlocks (generator.py:366-372). */
+ * one `dtype` output per alpha: the first activation of the parallel ResBlocks (generator.py:366-372).
+ * dtype CV_F32X3 = fp32-sized outputs in the pre-split chunk format of cv_gemm_params.x3_flags. */
 int cv_snake_multi(const float* x, int32_t rows, int32_t C, int32_t ldx, int32_t n, const float* const* alpha,
                    void* const* out, int32_t ldo, int32_t dtype, void* stream);
 
@@ -472,12 +479,13 @@ int cv_flow_euler_graph_destroy(void* graph);
  * `stages`, every `units` / `rbs` / `phases` / `xa` array are HOST arrays read at enqueue / capture time only. */
 typedef struct cv_hift_conv {        /* channels-last Conv1d: w [cout][k*cin] with k index = tap*cin + ci; cin = channel pitch of its input */
   const void* w; const float* b; int32_t k, cin, cout, dilation, pad_left, stride;
+  int32_t x3_flags, reserved;        /* gemm_dtype CV_F32X3: cv_gemm_params.x3_flags of this conv (bit 2 is dropped when it has no 16/32-bit activation output) */
 } cv_hift_conv;
 typedef struct cv_hift_resunit { cv_hift_conv c1, c2; const float* a1; const float* a2; } cv_hift_resunit;   /* Snake alphas [C] */
 typedef struct cv_hift_resblock { const cv_hift_resunit* units; int32_t n_units, reserved; } cv_hift_resblock;
 typedef struct cv_hift_phase { const void* w; int32_t ntaps, tap_base; } cv_hift_phase;   /* w [c][ntaps*up_cin] */
 typedef struct cv_hift_stage {
-  const cv_hift_phase* phases; const float* up_b; int32_t u, up_cin;
+  const cv_hift_phase* phases; const float* up_b; int32_t u, up_cin, up_flags, reserved;   /* up_flags: x3_flags of the phase GEMMs */
   cv_hift_conv source_down; cv_hift_resblock source_rb;
   const cv_hift_resblock* rbs;       /* [n_kernels] */
   int32_t t_out, c;                  /* frames and channels after this stage */
@@ -485,7 +493,9 @@ typedef struct cv_hift_stage {
   float* x32; void* const* xa; float* r0; float* r1; void* ta; void* ra; float* acc0; float* acc1; float* si0; float* si1; void* out;
 } cv_hift_stage;
 typedef struct cv_hift_decode_desc {
-  int32_t dtype, gemm_dtype, B, T, S, n_stages, n_kernels, stft_ld, hop; float lrelu_slope, audio_limit;
+  int32_t dtype, gemm_dtype, B, T, S, n_stages, n_kernels, stft_ld, hop;
+  int32_t presplit;                  /* != 0 (gemm_dtype CV_F32X3): activation tensors are kept in the pre-split chunk format (cv_snake_multi writes it too) */
+  float lrelu_slope, audio_limit;
   cv_hift_conv conv_pre, conv_post;
   const cv_hift_stage* stages;
   const void* mel_cl;                /* [B][T][conv_pre.cin] `dtype` (cv_to_channels_last of the mel) */

@@ -101,3 +101,24 @@ def test_stage_abi_decode_equals_python_composed_decode(tag, dt, mode):
     w_py = m.decode(mel, s).clone()
     torch.cuda.synchronize()
     assert torch.isfinite(w_abi).all() and w_abi.abs().max().item() > 0 and torch.equal(w_abi, w_py)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "v2"])
+def test_presplit_storage_is_bit_identical(tag, monkeypatch):
+    """bf16x3 decoder convs with PRE-SPLIT activation / weight storage (hi / lo bf16 planes per 4 values, written once by the producing
+    epilogue) against the plain bf16x3 launches that split every operand tile as it is staged: same hi / lo bits, same MFMAs."""
+    from cosyvoice_amd.hift import HiFTGenerator
+    cfg = CFGS[tag]
+    sd = hift_state_dict(cfg)
+    torch.manual_seed(5)
+    B, T = 2, 31
+    mel = torch.clamp(torch.randn(B, 80, T) * 2 - 6, -11.5, 2.0).cuda()
+    s = (torch.randn(B, 1, T * cfg.total_upsample) * 0.05).cuda()
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CV_HIFT_PRESPLIT", flag)
+        m = HiFTGenerator(cfg, dtype=torch.float32, f32_products="bf16x3").load_state_dict(sd)
+        assert m.presplit == (flag == "1")
+        outs[flag] = m.decode(mel, s).clone()
+    torch.cuda.synchronize()
+    assert outs["1"].abs().max().item() > 0 and torch.equal(outs["1"], outs["0"])
