@@ -75,6 +75,10 @@ class CosyVoice2Model:
         self.hift_cache_dict = {}
         self._llm_spans = {}      # uuid -> [start, end] wall-clock of the request's token loop (diagnostics / tests)
         self.overlap_hift = os.environ.get("CV_OVERLAP_HIFT", "0") != "0"   # tts_batches: HiFT of batch i on its own stream beside flow of batch i + 1 (measured SLOWER: 455 vs 548 audio-s/s — the vocoder GEMMs and the flow chain disturb each other on shared CUs; kept for experiments)
+        # tts_batches: where the decode jobs' prefills run.  True = on the flow CUs (throughput-bound GEMM work over B x 282 rows); False = on
+        # the decode CUs with the token loop.  Re-checked in round 2, when the flow + HiFT stream became the bottleneck: still better on the
+        # flow CUs (622-631 vs 605-612 audio-s/s) — on 64 CUs a 32-row prefill stalls both token loops for ~0.1 s per job
+        self.prefill_on_flow_cus = os.environ.get("CV_PREFILL_ON_FLOW", "1") != "0"
         self.pipeline_stats = None  # set to a list to collect (stage, batches, start, end) of every tts_batches job
 
     def load(self, llm_model, flow_model, hift_model):
@@ -362,7 +366,8 @@ class CosyVoice2Model:
                     # the prefill is throughput-bound GEMM work: it runs beside flow + HiFT on their (three times larger)
                     # CU share, the decode partition only runs the token loop
                     toks = ctx.generate_batch(cat("texts"), cat("prompt_texts"), cat("llm_prompt_speech_tokens"),
-                                              forced=forced, steps_per_poll=64, prefill_stream=None if borrow else pf)
+                                              forced=forced, steps_per_poll=64,
+                                              prefill_stream=None if (borrow or not self.prefill_on_flow_cus) else pf)
                 out, o = [], 0
                 for b in bs:
                     out.append(toks[o:o + len(b["texts"])])
