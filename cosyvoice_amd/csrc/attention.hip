@@ -195,12 +195,23 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const cv_attn_params p) {
         if (p.chunk > 0) jlim = min(jlim, (i / p.chunk + 1) * p.chunk);
         if (p.bias != nullptr) {
           const float* brow = p.bias + (int64_t)b * p.bias_bs + (int64_t)h * p.bias_hs + (int64_t)min(i, p.Tq - 1) * p.bias_ld;
+          // the lane's 16 bias values (two runs of 8 consecutive keys; the rel-pos view has no 16-byte alignment) as ONE batch of loads:
+          // written next to their use, hipcc paired every load with a vmcnt wait (16 dependent L2 round trips per q-tile)
+          float bv[4][4];
 #pragma unroll
           for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int j = j0 + ((kt >> 1) << 5) + (lg << 3) + ((kt & 1) << 2) + r;
-              const float v = fmaf(sacc[kt][qt][r], sc, brow[min(j, p.Tk - 1)] * 1.4426950408889634f);
+              bv[kt][r] = brow[min(j, p.Tk - 1)];
+            }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int j = j0 + ((kt >> 1) << 5) + (lg << 3) + ((kt & 1) << 2) + r;
+              const float v = fmaf(sacc[kt][qt][r], sc, bv[kt][r] * 1.4426950408889634f);
               sacc[kt][qt][r] = (j < jlim) ? v : NEG_BIG;
             }
         } else {

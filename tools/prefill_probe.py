@@ -1,7 +1,7 @@
 """Prefill (+ first token) wall time of Qwen2LM for NB utterances (env NB, default 8) and a forced GEMM tile (env CV_GEMM_TILE): what the
 decode jobs of tts_batches put on the flow CUs per job.  B = 8: 6.7 ms, B = 32: 18.8 ms (16.2 with the 8-wave 128x128 tile)."""
 import os, sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench as B
 from cosyvoice_amd.config import FlowConfig, LlmConfig
 from cosyvoice_amd.llm import Qwen2LM
