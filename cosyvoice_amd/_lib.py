@@ -258,7 +258,7 @@ EXPORTS = ["cv_version", "cv_arch", "cv_gemm", "cv_layernorm", "cv_attention",
            "cv_llm_step_graph_launch", "cv_llm_step_graph_destroy", "cv_sizeof_resblock_params", "cv_resblock_conv1", "cv_resblock_conv2",
            "cv_sizeof_flow_solver_desc", "cv_sizeof_flow_block", "cv_sizeof_flow_tblock", "cv_flow_euler_enqueue",
            "cv_flow_euler_graph_create", "cv_flow_euler_graph_launch", "cv_flow_euler_graph_destroy",
-           "cv_sizeof_hift_decode_desc", "cv_sizeof_hift_stage", "cv_sizeof_hift_resunit", "cv_hift_decode_enqueue",
+           "cv_sizeof_hift_decode_desc", "cv_sizeof_hift_stage", "cv_sizeof_hift_resunit", "cv_hift_decode_enqueue", "cv_hift_decode",
            "cv_hift_decode_graph_create"]
 
 TORCH_DT = {torch.float32: CV_F32, torch.bfloat16: CV_BF16, torch.float16: CV_F16}

@@ -386,6 +386,9 @@ extern "C" int cv_hift_decode_enqueue(const cv_hift_decode_desc* d, void* stream
   return enqueue_hift_decode(*d, (hipStream_t)stream);
 }
 
+// SURVEY.md §8b names the entry point cv_hift_decode: same call
+extern "C" int cv_hift_decode(const cv_hift_decode_desc* d, void* stream) { return cv_hift_decode_enqueue(d, stream); }
+
 extern "C" int cv_hift_decode_graph_create(const cv_hift_decode_desc* d, void* capture_stream, void** graph_out) {
   if (!graph_out || !capture_stream) return CV_ERR_ARG;
   if (int rc = check_hift_desc(d)) return rc;

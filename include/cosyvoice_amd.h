@@ -509,6 +509,7 @@ int cv_sizeof_hift_decode_desc(void);
 int cv_sizeof_hift_stage(void);
 int cv_sizeof_hift_resunit(void);
 int cv_hift_decode_enqueue(const cv_hift_decode_desc* d, void* stream);
+int cv_hift_decode(const cv_hift_decode_desc* d, void* stream);   /* = cv_hift_decode_enqueue (the name SURVEY.md §8b lists) */
 int cv_hift_decode_graph_create(const cv_hift_decode_desc* d, void* capture_stream, void** graph_out);
 
 int cv_sizeof_gemm_params(void);
