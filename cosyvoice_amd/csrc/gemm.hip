@@ -625,6 +625,9 @@ int dispatch(const cv_gemm_params& p, hipStream_t st) {
     const long long t12864 = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * p.batch;
     if (p.K > 512 && t12864 >= 768) tile = 1;
     else tile = 2;
+    // very tall GEMMs with wide N and K (the LLM prefill of a 4-batch decode job: 9 024 rows): the 8-wave 128 x 128 tile halves the
+    // operand bytes per flop (tools/prefill_probe.py: 18.8 -> 16.2 ms at 32 sequences; slower at 8 sequences = 2 256 rows)
+    if (p.batch == 1 && p.M >= 8192 && p.N >= 512 && p.K >= 512) tile = 4;
   }
   if (swiglu && (tile == 0 || tile == 3)) tile = 1;
   if (tile == 3) return launch_ring<DT>(p, st);

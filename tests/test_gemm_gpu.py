@@ -102,3 +102,25 @@ def test_layernorm(odt, rows, dim, rms):
     torch.cuda.synchronize()
     assert (o32 - ref).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-5
     assert _rel(oa, ref) < {torch.float32: 1e-6, torch.bfloat16: 5e-3, torch.float16: 6e-4}[odt]
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_tall_gemm_tile_plain_and_swiglu(dt):
+    """>= 8192 rows with N, K >= 512 take the 8-wave 128 x 128 tile (the LLM prefill of a 4-batch decode job): plain epilogue with a
+    residual, and the SwiGLU epilogue over [gate16 | up16]-interleaved weights (the prefill's gate/up GEMM)."""
+    from cosyvoice_amd import ops
+    torch.manual_seed(1)
+    dev, M, K, I = "cuda", 9024, 896, 1024
+    x = (torch.randn(M, K, device=dev) * 0.5).to(dt)
+    W = (torch.randn(896, K, device=dev) / K ** 0.5).to(dt)
+    res = torch.randn(M, 896, device=dev)
+    o32 = torch.empty(M, 896, device=dev)
+    ops.linear(x, W, res=res, out_f32=o32)
+    g = (torch.randn(I, K, device=dev) / K ** 0.5).to(dt)
+    u = (torch.randn(I, K, device=dev) / K ** 0.5).to(dt)
+    gu = torch.stack([g.view(I // 16, 16, K), u.view(I // 16, 16, K)], dim=1).reshape(2 * I, K).contiguous()
+    h = torch.empty(M, I, device=dev, dtype=dt)
+    ops.linear(x, gu, act=ops.ACT_SWIGLU, out_act=h)
+    torch.cuda.synchronize()
+    assert _rel(o32, x.float() @ W.float().t() + res) < TOL[dt] * 0.5
+    assert _rel(h, F.silu(x.float() @ g.float().t()) * (x.float() @ u.float().t())) < TOL[dt]
