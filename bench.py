@@ -414,10 +414,18 @@ def measure_attention_roofline(flow, B):
     dur = ev_time(g.launch, 5, warm=2) / n
     g.destroy()
     flops = 4.0 * R * H * T * T * 64
+    traffic, alg_bytes = None, 4 * R * T * H * 64 * 2   # Q, K, V^T read + O written once, 16-bit
+    pmc = os.path.join(ROOT, "profiles", "r02_f_tblock_hbm.json")   # separate --pmc FETCH_SIZE / WRITE_SIZE passes at this shape (R = 16, T = 1000)
+    if os.path.exists(pmc) and (R, T) == (16, 1000):
+        try:
+            traffic = json.load(open(pmc))["kernels"]["attn_kernel<2>"]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
     return {"bound": "mfma", "kernel": f"attn_kernel<f16> (flow estimator flash attention, {R} rows x {H} heads x T={T}, head_dim 64)",
             "achieved": round(flops / dur / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flops / dur / 2.5e15, 4),
-            "traffic": None, "flops_per_launch": flops, "avg_launch_us": round(dur * 1e6, 2),
-            "note": "algorithmic flops per launch = 4 R H T^2 d (QK^T and PV), SURVEY.md §8d's 2048 T flop per row per block"}
+            "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "flops_per_launch": flops, "avg_launch_us": round(dur * 1e6, 2),
+            "note": "algorithmic flops per launch = 4 R H T^2 d (QK^T and PV), SURVEY.md §8d's 2048 T flop per row per block; traffic = HBM bytes per "
+                    "launch from PMC (2 x FETCH_SIZE + WRITE_SIZE): every (row, head)'s K / V^T is fetched once (one XCD per head)"}
 
 
 def measure_decode_roofline(llm, lc, rows=UTT_PER_GPU):
