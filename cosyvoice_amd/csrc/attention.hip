@@ -93,8 +93,8 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const cv_attn_params p) {
   u32x4_t rk[2], rv[2];
   int tile_j0 = 0;  // key offset of the prefetched tile (the V^T tail mask is applied when it is written to LDS)
   const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)Kp, 0, klen > 0 ? ((klen - 1) * p.ldk + 64) * 2 : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)Vt, 0, 64 * p.vt_ld * 2, 0x00020000);
+      (void*)Kp, 0, klen > 0 ? (int)min(((int64_t)(klen - 1) * p.ldk + 64) * 2, (int64_t)0x7FFFFFFF) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)Vt, 0, (int)min((int64_t)64 * p.vt_ld * 2, (int64_t)0x7FFFFFFF), 0x00020000);
   int koff[2], voff[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -349,6 +349,7 @@ extern "C" int cv_attention(const cv_attn_params* pp, void* stream) {
   if (!p.q || !p.k || !p.vt || !p.out) return CV_ERR_ARG;
   if ((p.ldq & 7) || (p.ldk & 7) || (p.vt_ld & 7) || (p.ldo & 3) || (p.q_bs & 7) || (p.k_bs & 7) || (p.o_bs & 3)) return CV_ERR_ARG;
   if (p.vt_ld < p.Tk) return CV_ERR_ARG;
+  if ((int64_t)p.Tk * p.ldk * 2 >= (int64_t)1 << 31 || (int64_t)64 * p.vt_ld * 2 >= (int64_t)1 << 31) return CV_ERR_UNSUPPORTED;   // 32-bit buffer offsets per (batch, head)
   if (((uintptr_t)p.q & 15) || ((uintptr_t)p.k & 15) || ((uintptr_t)p.vt & 15) || ((uintptr_t)p.out & 7)) return CV_ERR_ARG;
   dim3 grid(p.H, (p.Tq + 127) / 128, p.B);
   hipStream_t st = (hipStream_t)stream;
