@@ -506,11 +506,17 @@ class Qwen2LM:
 
     # teacher-forced log-probs for parity tests (not on the product path of tts())
     @torch.no_grad()
-    def forced_logits(self, text, prompt_text, prompt_speech, forced: List[int]) -> torch.Tensor:
-        """Returns (len(forced)+1, V) log-softmax rows: prefill + one row per forced token (SURVEY.md H1 parity contract)."""
+    def forced_logits(self, text, prompt_text, prompt_speech, forced: List[int], rows: int = 1,
+                      keep: Optional[List[int]] = None) -> torch.Tensor:
+        """Returns (len(forced)+1, V) log-softmax rows: prefill + one row per forced token (SURVEY.md H1 parity contract).
+        ``rows`` > 1: the same sequence in every one of ``rows`` batch rows (the launch shapes of a batched token loop: 8-row,
+        16-row and two-row-group skinny kernels, batched decode attention), result (n, rows, V).  ``keep``: only these step
+        indices are returned (in that order)."""
         st = self.st
-        B = 1
+        B = rows
+        assert 1 <= B <= self.max_batch and len(forced) + 1 <= self.max_out
         Lp = 1 + prompt_text.numel() + text.numel() + 1 + prompt_speech.numel()
+        assert Lp + len(forced) + 1 <= self.ctx_max, "ctx_max too small"
         ws = self._prefill_workspace(B, Lp)
         for k in ("step", "n_emitted", "finished"):
             st[k].zero_()
@@ -518,13 +524,18 @@ class Qwen2LM:
         st["min_len"].fill_(0)
         st["max_len"].fill_(len(forced) + 8)
         f = torch.full((self.R, self.max_out), -2, dtype=torch.int32)
-        f[0, :len(forced)] = torch.tensor(forced, dtype=torch.int32)
+        f[:B, :len(forced)] = torch.tensor(forced, dtype=torch.int32)
         st["forced"].copy_(f)
-        self._assemble_inputs(ws, [text], [prompt_text], [prompt_speech], B, Lp)
-        out = []
+        self._assemble_inputs(ws, [text] * B, [prompt_text] * B, [prompt_speech] * B, B, Lp)
+        want = set(range(len(forced) + 1)) if keep is None else set(keep)
+        got = {}
         self._prefill(B, Lp, True, False)
-        out.append(st["logits"][0, :self.cfg.out_vocab].clone())
-        for _ in range(len(forced)):
+        if 0 in want:
+            got[0] = st["logits"][:B, :self.cfg.out_vocab].clone()
+        for i in range(1, len(forced) + 1):
             self._step(B, True, False)
-            out.append(st["logits"][0, :self.cfg.out_vocab].clone())
-        return torch.stack(out).log_softmax(dim=-1)
+            if i in want:
+                got[i] = st["logits"][:B, :self.cfg.out_vocab].clone()
+        order = list(range(len(forced) + 1)) if keep is None else list(keep)
+        lp = torch.stack([got[i] for i in order]).log_softmax(dim=-1)
+        return lp[:, 0] if rows == 1 else lp

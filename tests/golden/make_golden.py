@@ -698,6 +698,30 @@ def golden_llm_loop():
         del lm
 
 
+LLM_LONG_ROWS = (0, 1, 63, 127, 229, 230, 231, 249, 250)
+
+
+def golden_llm_long():
+    """FULL-size LM at the context the C4 bench line runs: prefill L = 1 + 10 + 20 + 1 + 250 = 282, then 250
+    teacher-forced steps through the reference's own Qwen2LM.inference loop (llm/llm.py:823-874), so the attended context grows
+    282 -> 532 and crosses 512 keys at row 230.  Kept: the log-prob rows LLM_LONG_ROWS (row i = distribution after i forced tokens,
+    i.e. over 282 + i keys) and the last-position summary of lm_input."""
+    from cosyvoice_amd.config import LlmConfig
+    from cosyvoice_amd.weights import llm_state_dict
+    cfg = LlmConfig.full()
+    lm = build_ref_llm(cfg, llm_state_dict(cfg))
+    g = torch.Generator().manual_seed(53)
+    text = torch.randint(0, cfg.vocab_size, (1, 20), generator=g, dtype=torch.int32)
+    prompt_text = torch.randint(0, cfg.vocab_size, (1, 10), generator=g, dtype=torch.int32)
+    prompt_speech = torch.randint(0, cfg.speech_token_size, (1, 250), generator=g, dtype=torch.int32)
+    forced = torch.randint(0, cfg.speech_token_size, (250,), generator=g).tolist()
+    lm_input, logps = _ref_lm_inference_capture(lm, text, prompt_text, prompt_speech, forced, cfg.speech_token_size)
+    assert lm_input.shape[1] == 282 and logps.shape[0] == 251
+    rows = np.array(LLM_LONG_ROWS, dtype=np.int64)
+    save("llm_full_long", text=text, prompt_text=prompt_text, prompt_speech=prompt_speech, forced=np.array(forced), rows=rows,
+         lm_input_summary=summary(lm_input), logps=logps[torch.from_numpy(rows)])
+
+
 def golden_sampler_ref():
     """The reference's OWN sampling functions (utils/common.py:105-146: ras_sampling, non_random_ras_sampling, nucleus_sampling,
     random_sampling) called as they are, with torch.Tensor.multinomial replaced by an inverse-CDF draw from recorded uniforms
@@ -775,6 +799,55 @@ def golden_flow_full():
     save("flow_full", **out)
 
 
+def golden_flow_long():
+    """FULL-depth reference flow at the length of the C4 bench line: N_p = 250 prompt tokens + N_g = 250 generated tokens -> T = 1000
+    frames through CausalMaskedDiffWithXvec.inference (flow/flow.py:258-319), encoder chunk mask 50 (CosyVoice2Model, cli/model.py:314),
+    56 estimator blocks x 10 CFG Euler steps.  The returned mel is (1, 80, 500); the fixture keeps the exact fp32 mel on every 4th
+    frame plus the per-channel abs-means and per-frame means of the whole mel."""
+    from cosyvoice_amd.config import FlowConfig
+    from cosyvoice_amd.weights import flow_state_dict
+    cfg = FlowConfig.full()
+    flow = build_ref_flow(cfg, flow_state_dict(cfg))
+    g = torch.Generator().manual_seed(67)
+    n_p, n_g = 250, 250
+    token = torch.randint(0, cfg.vocab_size, (1, n_g), generator=g, dtype=torch.int32)
+    prompt_token = torch.randint(0, cfg.vocab_size, (1, n_p), generator=g, dtype=torch.int32)
+    prompt_feat = torch.clamp(torch.randn(1, 2 * n_p, 80, generator=g) * 2 - 6, -11.5, 2.0)
+    embedding = torch.randn(1, cfg.spk_embed_dim, generator=g)
+    flow.encoder.static_chunk_size = 50
+    with torch.inference_mode():
+        mel, _ = flow.inference(token=token, token_len=torch.tensor([n_g]), prompt_token=prompt_token,
+                                prompt_token_len=torch.tensor([n_p]), prompt_feat=prompt_feat,
+                                prompt_feat_len=torch.tensor([2 * n_p]), embedding=embedding)
+    assert mel.shape == (1, 80, 2 * n_g), mel.shape
+    print("flow long", tuple(mel.shape), summary(mel))
+    save("flow_long", token=token, prompt_token=prompt_token, prompt_feat=prompt_feat, embedding=embedding,
+         mel_sub4=mel[:, :, ::4].contiguous(), mel_chan_absmean=mel[0].abs().mean(dim=1), mel_frame_mean=mel[0].mean(dim=0),
+         mel_summary=summary(mel))
+
+
+def golden_hift_long():
+    """Reference HiFTGenerator.decode (hifigan/generator.py:349-381) at the BASELINE lengths: v2 (24 kHz) 500 frames -> 240 000 samples,
+    v1 (22.05 kHz) 861 frames -> 220 416 samples, injected source s.  The waveform is kept on every 8th sample (exact fp32) plus
+    per-2400-sample block abs-means / abs-maxima of the whole waveform; the inputs are regenerated from their seeds by the test."""
+    from cosyvoice_amd.config import HiftConfig
+    for tag, cfg, frames in (("v2", HiftConfig.v2(), 500), ("v1", HiftConfig.v1(), 861)):
+        from cosyvoice_amd.weights import hift_state_dict
+        m = build_ref_hift(cfg, hift_state_dict(cfg))
+        mel = synth_mel(1, frames, seed=211)
+        g = torch.Generator().manual_seed(212)
+        s = torch.randn(1, 1, frames * cfg.total_upsample, generator=g) * 0.05
+        with torch.inference_mode():
+            wav = m.decode(x=mel, s=s)
+            f0 = m.f0_predictor(mel)
+        n = wav.shape[1]
+        blk = wav[0, : n // 2400 * 2400].view(-1, 2400).abs() if n >= 2400 else wav.abs()
+        print("hift long", tag, tuple(wav.shape), summary(wav))
+        save(f"hift_{tag}_long", frames=np.array(frames), mel_seed=np.array(211), s_seed=np.array(212), n_samples=np.array(n),
+             wav_sub8=wav[:, ::8].contiguous(), wav_block_absmean=blk.mean(dim=1), wav_block_absmax=blk.max(dim=1).values,
+             f0=f0, wav_summary=summary(wav))
+
+
 def golden_stream_v2():
     """The reference's own CosyVoice2Model (cli/model.py:295-424) streaming path: tts(stream=True) with a stub LLM that emits a
     fixed token list and a stub vocoder that records the speech_feat / cache_source it is handed (the real HiFT draws random
@@ -835,7 +908,7 @@ def main():
     torch.set_num_threads(8)
     install_stubs()
     which = sys.argv[1:] or ["hift", "flow", "llm", "bigvgan", "frontend", "phoneme", "v1orch", "llmv1", "flowv1", "llmloop", "samplerref",
-                             "flowfull", "streamv2"]
+                             "flowfull", "streamv2", "llmlong", "flowlong", "hiftlong"]
     if "hift" in which:
         golden_hift()
     if "flow" in which:
@@ -863,6 +936,12 @@ def main():
         golden_flow_full()
     if "streamv2" in which:
         golden_stream_v2()
+    if "llmlong" in which:
+        golden_llm_long()
+    if "flowlong" in which:
+        golden_flow_long()
+    if "hiftlong" in which:
+        golden_hift_long()
 
 
 if __name__ == "__main__":

@@ -271,3 +271,51 @@ def test_flow_full_depth_vs_reference(golden_dir, tag, chunk, key):
     d = (m - ref).abs()
     assert d.max().item() < 2e-4 and d.mean().item() < 2e-5, (d.max().item(), d.mean().item())
     assert (m[0].abs().mean(dim=1) - g[f"{tag}_mel_{key}_chan_absmean"]).abs().max().item() < 2e-5
+
+
+# ----------------------------------------------------------------------------- round 3: goldens at the lengths the C4 bench line runs
+def _synth_mel(batch, frames, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.clamp(torch.randn(batch, 80, frames, generator=g) * 2.0 - 6.0, -11.5, 2.0)
+
+
+@pytest.mark.parametrize("tag,cfg", [("v2", HiftConfig.v2()), ("v1", HiftConfig.v1())])
+def test_hift_decode_baseline_length(golden_dir, tag, cfg):
+    """oracle decode at 500 (v2) / 861 (v1) frames vs the reference's own HiFTGenerator.decode (every 8th sample exact + block stats)."""
+    g = _load(golden_dir, f"hift_{tag}_long")
+    frames = int(g["frames"])
+    mel = _synth_mel(1, frames, int(g["mel_seed"]))
+    s = torch.randn(1, 1, frames * cfg.total_upsample, generator=torch.Generator().manual_seed(int(g["s_seed"]))) * 0.05
+    sd = hift_state_dict(cfg)
+    wav = oh.decode(sd, cfg, mel, s)
+    assert wav.shape[1] == int(g["n_samples"])
+    assert (wav[:, ::8] - g["wav_sub8"]).abs().max().item() < 1e-5
+    blk = wav[0, : wav.shape[1] // 2400 * 2400].view(-1, 2400).abs()
+    assert (blk.mean(dim=1) - g["wav_block_absmean"]).abs().max().item() < 1e-6
+    assert (blk.max(dim=1).values - g["wav_block_absmax"]).abs().max().item() < 1e-5
+    assert (oh.f0_predictor(sd, mel) - g["f0"]).abs().max().item() < 1e-3
+
+
+def test_flow_inference_baseline_length(golden_dir):
+    """oracle CausalMaskedDiffWithXvec.inference at T = 1000 (250 + 250 tokens, chunk mask 50, 56 blocks x 10 steps) vs the reference."""
+    cfg = FlowConfig.full()
+    g = _load(golden_dir, "flow_long")
+    m = of.inference(flow_state_dict(cfg), cfg, g["token"], g["prompt_token"], g["prompt_feat"], g["embedding"], static_chunk_size=50)
+    assert m.shape == (1, 80, 500)
+    assert (m[:, :, ::4] - g["mel_sub4"]).abs().max().item() < 2e-4   # fp32 summation order over 10 steps x 56 blocks; values up to 5.9
+    assert (m[:, :, ::4] - g["mel_sub4"]).abs().mean().item() < 1e-5
+    assert (m[0].abs().mean(dim=1) - g["mel_chan_absmean"]).abs().max().item() < 1e-5
+    assert (m[0].mean(dim=0) - g["mel_frame_mean"]).abs().max().item() < 2e-5
+
+
+def test_llm_long_context_logp(golden_dir):
+    """oracle Qwen2 loop at prefill 282 + 250 teacher-forced steps (context 282 -> 532) vs the reference's own inference loop."""
+    cfg = LlmConfig.full()
+    g = _load(golden_dir, "llm_full_long")
+    forced = g["forced"].tolist()
+    lp = []
+    toks = list(ol.lm_inference(llm_state_dict(cfg), cfg, g["text"], g["prompt_text"], g["prompt_speech"], uniforms=lambda t: (0.5, 0.5),
+                                forced_tokens=forced, collect_logp=lp))
+    assert toks == forced and len(lp) == 251
+    lp = torch.stack(lp)[g["rows"]]
+    assert (lp - g["logps"]).abs().max().item() < 1e-4
