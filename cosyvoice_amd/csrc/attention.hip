@@ -8,6 +8,7 @@
 //   * V arrives pre-transposed (V^T [d][key], written by the QKV producer), so its A fragment is ONE 16-byte
 //     LDS read per lane from a [64 d][128 B] image with XOR-swizzled 16-byte chunk slots.
 // K / V^T tiles (64 keys) are staged through LDS, double-buffered with register prefetch (one barrier per tile).
+#include <cstdlib>
 #include <type_traits>
 #include "cv_device.h"
 
@@ -34,8 +35,11 @@ __device__ __forceinline__ float xlane_max(float v) {
 
 // launch bound 3 workgroups per CU (168 VGPRs, no spills): the kernel is stall-bound, not issue-bound (3 600 cycles per
 // tile-wave against ~900 of issue), so a third resident wave per SIMD bought 97 -> 83 us; a fourth needs 128 VGPRs and spills.
-template <int DT>
-__global__ __launch_bounds__(256, 3) void attn_kernel(const cv_attn_params p) {
+// NWV = waves per workgroup: 4 (128 queries; the batch-8 shapes) or 2 (64 queries: twice the workgroups for grids that would
+// leave most of the chip idle — one utterance, R = 2 CFG rows x 8 heads x T / 128 query blocks is 64 - 128 workgroups on 256 CUs).
+template <int DT, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 2) void attn_kernel(const cv_attn_params p) {
+  constexpr int NT = 64 * NWV, QW = 32 * NWV, NL = 512 / NT;   // threads, queries per workgroup, 16-byte chunks per thread per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform (tile counts and buffer soffsets derive from it)
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const cv_attn_params p) {
   // all query blocks of one (batch, head) run on ONE XCD and its K / V^T (256 KB at T = 1000) is fetched into one L2, not eight.
   const int b = blockIdx.z, h = blockIdx.x;
   const int hk = h / (p.H / p.Hkv);
-  const int q_wg = blockIdx.y * 128;
+  const int q_wg = blockIdx.y * QW;
   const int q0 = q_wg + wid * 32;
 
   const uint16_t* Q = (const uint16_t*)p.q + (int64_t)b * p.q_bs + h * p.q_hs;
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const cv_attn_params p) {
 
   // keys this workgroup can ever need
   int limit = klen;
-  const int q_max = min(p.Tq, q_wg + 128) - 1;
+  const int q_max = min(p.Tq, q_wg + QW) - 1;
   if (p.causal) limit = min(limit, q_max + p.causal_off + 1);
   if (p.chunk > 0) limit = min(limit, (q_max / p.chunk + 1) * p.chunk);
   const int ntiles = (limit + 63) >> 6;
@@ -90,15 +94,15 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const cv_attn_params p) {
 
   // K / V^T tile loads go through buffer descriptors: the per-thread offset is fixed, the tile offset is an SGPR (no
   // per-tile address VALU), and K rows >= klen fall outside num_records and read as zeros (no clamp, no mask).
-  u32x4_t rk[2], rv[2];
+  u32x4_t rk[NL], rv[NL];
   int tile_j0 = 0;  // key offset of the prefetched tile (the V^T tail mask is applied when it is written to LDS)
   const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)Kp, 0, klen > 0 ? (int)min(((int64_t)(klen - 1) * p.ldk + 64) * 2, (int64_t)0x7FFFFFFF) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)Vt, 0, (int)min((int64_t)64 * p.vt_ld * 2, (int64_t)0x7FFFFFFF), 0x00020000);
-  int koff[2], voff[2];
+  int koff[NL], voff[NL];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = i * 256 + tid;
+  for (int i = 0; i < NL; ++i) {
+    const int c = i * NT + tid;
     const int r = c >> 3, dc = c & 7;  // K: 8 consecutive lanes = one 128-byte key row; V^T: r = d row, dc = key chunk
     koff[i] = (r * p.ldk + dc * 8) * 2;
     voff[i] = (r * p.vt_ld + dc * 8) * 2;
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const cv_attn_params p) {
     const int j0 = t << 6;
     tile_j0 = j0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NL; ++i) {
       rk[i] = __builtin_amdgcn_raw_buffer_load_b128(k_rs, koff[i], j0 * p.ldk * 2, 0);
       rv[i] = __builtin_amdgcn_raw_buffer_load_b128(v_rs, voff[i], j0 * 2, 0);
     }
@@ -117,8 +121,8 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const cv_attn_params p) {
     char* sv = sk + KT_BYTES;
     const bool tail = tile_j0 + 64 > klen;  // wave-uniform: only the last tile of a sequence needs the V^T key mask
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = i * 256 + tid;
+    for (int i = 0; i < NL; ++i) {
+      const int c = i * NT + tid;
       const int r = c >> 3, dc = c & 7;
       *(u32x4_t*)(sk + (r << 7) + ((dc ^ kswz(r)) << 4)) = rk[i];  // row-major, XOR-swizzled chunk slot
       u32x4_t u = rv[i];
@@ -351,11 +355,22 @@ extern "C" int cv_attention(const cv_attn_params* pp, void* stream) {
   if (p.vt_ld < p.Tk) return CV_ERR_ARG;
   if ((int64_t)p.Tk * p.ldk * 2 >= (int64_t)1 << 31 || (int64_t)64 * p.vt_ld * 2 >= (int64_t)1 << 31) return CV_ERR_UNSUPPORTED;   // 32-bit buffer offsets per (batch, head)
   if (((uintptr_t)p.q & 15) || ((uintptr_t)p.k & 15) || ((uintptr_t)p.vt & 15) || ((uintptr_t)p.out & 7)) return CV_ERR_ARG;
-  dim3 grid(p.H, (p.Tq + 127) / 128, p.B);
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = 2 * STAGE_BYTES;
-  if (p.dtype == CV_BF16) hipLaunchKernelGGL(attn_kernel<CV_BF16>, grid, dim3(256), lds, st, p);
-  else hipLaunchKernelGGL(attn_kernel<CV_F16>, grid, dim3(256), lds, st, p);
+  // 64-query workgroups when 128-query ones would not even fill the chip once (CV_ATTN_WAVES=2|4 overrides: tuning aid)
+  const char* fe = getenv("CV_ATTN_WAVES");   // read per call: tests switch it
+  const int forced = fe ? atoi(fe) : 0;
+  const int64_t wgs4 = (int64_t)p.H * ((p.Tq + 127) / 128) * p.B;
+  const bool two = forced == 2 || (forced != 4 && wgs4 < 256);
+  if (two) {
+    dim3 grid(p.H, (p.Tq + 63) / 64, p.B);
+    if (p.dtype == CV_BF16) hipLaunchKernelGGL((attn_kernel<CV_BF16, 2>), grid, dim3(128), lds, st, p);
+    else hipLaunchKernelGGL((attn_kernel<CV_F16, 2>), grid, dim3(128), lds, st, p);
+  } else {
+    dim3 grid(p.H, (p.Tq + 127) / 128, p.B);
+    if (p.dtype == CV_BF16) hipLaunchKernelGGL((attn_kernel<CV_BF16, 4>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((attn_kernel<CV_F16, 4>), grid, dim3(256), lds, st, p);
+  }
   CV_CHECK_LAUNCH();
   return CV_OK;
 }

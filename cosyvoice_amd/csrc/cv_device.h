@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/cosyvoice_amd.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -13,6 +14,18 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
     hipError_t e__ = hipGetLastError();                    \
     if (e__ != hipSuccess) return CV_ERR_LAUNCH;           \
   } while (0)
+
+// Host side: a per-function attribute such as the > 64 KiB dynamic-LDS opt-in (hipFuncSetAttribute) applies to the CURRENT device.
+// Remembered per (call site, device); whichever thread gets to a new device first sets it (setting it twice is harmless).
+struct PerDeviceOnce {
+  std::atomic<bool> done[64];
+  PerDeviceOnce() { for (auto& d : done) d.store(false, std::memory_order_relaxed); }
+  template <typename F> void run(F&& f) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { f(); return; }
+    if (!done[dev].load(std::memory_order_acquire)) { f(); done[dev].store(true, std::memory_order_release); }
+  }
+};
 
 template <typename To, typename From>
 __device__ __forceinline__ To bitcast(const From& f) {

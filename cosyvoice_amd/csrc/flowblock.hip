@@ -34,6 +34,7 @@
 // (rows beyond T dropped by the bounds check) because stores under an exec-masked branch make the in-order vmcnt
 // bookkeeping of the prefetched loads conservative.
 #include "cv_device.h"
+#include <climits>
 #include <cstdlib>
 
 namespace {
@@ -81,6 +82,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t frag_rsrc(const void* base, in
 // "redefine" 8 registers at this point: every load that fills them has to be issued before it (hipcc otherwise sinks each
 // load of a batch to its own consumer and pays one dependent L2 round trip per row)
 #define PIN8(v) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]))
+#define PIN6(v) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]))
+#define PIN4(v) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]))
+#define PIN2(v) asm volatile("" : "+v"(v[0]), "+v"(v[1]))
+template <int N, typename V>
+__device__ __forceinline__ void pin_regs(V (&v)[N]) {
+  static_assert(N == 2 || N == 4 || N == 6 || N == 8, "pin_regs");
+  if constexpr (N == 8) PIN8(v);
+  else if constexpr (N == 6) PIN6(v);
+  else if constexpr (N == 4) PIN4(v);
+  else PIN2(v);
+}
 
 template <int DT>
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
@@ -96,15 +108,15 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-// LayerNorm of this workgroup's 64 rows straight from global memory into the K = 256 operand image (512-byte rows):
-// wave w normalises rows 8 w .. 8 w + 7, four rows per pass, 16 lanes per row (lane sub = l & 15 holds columns
-// 64 k + 4 sub ..+3, k < 4: 256-byte coalesced segments), two-pass in registers, row sums by DPP.
+// LayerNorm of this workgroup's rows straight from global memory into the K = 256 operand image (512-byte rows):
+// wave w normalises rows RPW w .. RPW w + RPW - 1 (RPW = 8 for 48 / 64-row tiles, 4 for 16 / 32-row tiles: the image always
+// holds a multiple of 32 rows), four rows per pass, 16 lanes per row (lane sub = l & 15 holds columns 64 k + 4 sub ..+3, k < 4:
+// 256-byte coalesced segments), two-pass in registers, row sums by DPP.
 // Rows beyond T re-read row T-1 (finite values; their results are never stored).
-template <int DT>
+template <int DT, int MT>
 __device__ __forceinline__ void ln_rows_to_lds(const float* xs, int ldx, int t0, int T, const float* gamma, const float* beta,
                                                float eps, char* img, int wid, int lane) {
-  constexpr int RPW = BM / NW, NP = RPW / 4;   // 8 rows per wave, 2 passes
-  static_assert(NP * 4 == 8, "PIN8 covers two passes");
+  constexpr int NP = (16 * MT + 4 * NW - 1) / (4 * NW), RPW = 4 * NP;   // passes per wave (1 or 2), rows per wave
   const int sub = lane & 15, rr = lane >> 4;
   f32x4_t v[NP * 4];   // [pass][k]
 #pragma unroll
@@ -119,7 +131,7 @@ __device__ __forceinline__ void ln_rows_to_lds(const float* xs, int ldx, int t0,
     g4[k] = *(const float4*)(gamma + 64 * k + 4 * sub);
     b4[k] = *(const float4*)(beta + 64 * k + 4 * sub);
   }
-  PIN8(v);
+  pin_regs(v);
 #pragma unroll
   for (int ps = 0; ps < NP; ++ps) {
     float s = 0.f;
@@ -176,7 +188,7 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_head_kernel(const cv_tblock_pa
   };
   ld(s[0], 0);
   ld(s[1], 1);
-  ln_rows_to_lds<DT>(xs, p.ldx, t0, p.T, p.g1, p.b1n, p.eps, smem, wid, lane);
+  ln_rows_to_lds<DT, MT>(xs, p.ldx, t0, p.T, p.g1, p.b1n, p.eps, smem, wid, lane);
   ld(s[2], 2);
   ld(s[3], 3);
   __syncthreads();
@@ -339,20 +351,21 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_tail_kernel(const cv_tblock_pa
       __builtin_amdgcn_sched_barrier(0);
     };
     {
-      // ---- attention output tile -> LDS operand image (1024-byte rows), one row per wave-instruction, 8 rows per wave
-      u32x4_t v[8];
+      // ---- attention output tile -> LDS operand image (1024-byte rows), one row per wave-instruction, 2 MT rows per wave
+      constexpr int AR = 2 * MT;
+      u32x4_t v[AR];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int t = min(t0 + wid * 8 + i, p.T - 1);
+      for (int i = 0; i < AR; ++i) {
+        const int t = min(t0 + wid * AR + i, p.T - 1);
         v[i] = *(const u32x4_t*)(aos + (int64_t)t * p.ldao + lane * 8);
       }
       __builtin_amdgcn_sched_barrier(0);
       ld_o(s[0], 0);
       ld_o(s[1], 1);
-      PIN8(v);
+      pin_regs(v);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = wid * 8 + i;
+      for (int i = 0; i < AR; ++i) {
+        const int row = wid * AR + i;
         *(u32x4_t*)(smem + row * 1024 + (swz16(row, lane) << 4)) = v[i];
       }
     }
@@ -434,7 +447,7 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_tail_kernel(const cv_tblock_pa
   } else {
     ld_ffn(s[0], 0);
     ld_ffn(s[1], 1);
-    ln_rows_to_lds<DT>(xs, p.ldx, t0, p.T, p.g3, p.b3n, p.eps, ximg, wid, lane);
+    ln_rows_to_lds<DT, MT>(xs, p.ldx, t0, p.T, p.g3, p.b3n, p.eps, ximg, wid, lane);
     ld_ffn(s[2], 2);
     ld_ffn(s[3], 3);
     load_residual();
@@ -772,8 +785,8 @@ void set_lds(K kern, size_t lds) { hipFuncSetAttribute((const void*)kern, hipFun
 constexpr size_t TAIL_LDS = 98304 + 4096 + 4096 + 4096;
 template <int DT, bool OP, int MT, int ABL>
 void launch_tail(const cv_tblock_params& p, hipStream_t st) {
-  static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in
-  if (!attr_set) { set_lds(tblock_tail_kernel<DT, OP, MT, ABL>, TAIL_LDS); attr_set = true; }
+  static PerDeviceOnce once;   // > 64 KiB of dynamic LDS needs the opt-in
+  once.run([] { set_lds(tblock_tail_kernel<DT, OP, MT, ABL>, TAIL_LDS); });
   dim3 grid((p.T + 16 * MT - 1) / (16 * MT), p.R);
   hipLaunchKernelGGL((tblock_tail_kernel<DT, OP, MT, ABL>), grid, dim3(NTHR), TAIL_LDS, st, p);
 }
@@ -782,14 +795,27 @@ void launch_head(const cv_tblock_params& p, hipStream_t st) {
   dim3 grid((p.T + 16 * MT - 1) / (16 * MT), p.R);
   hipLaunchKernelGGL((tblock_head_kernel<DT, MT, ABL>), grid, dim3(NTHR), 32768, st, p);
 }
-// rows per tile: the one that minimises (rounds of workgroups over the CUs the launch may use) x (rows per tile); one workgroup
-// per CU is resident.  p.cus = 0 means the whole chip.  CV_TBLOCK_MT=3|4 overrides (tuning aid).
+// rows per tile (16 MT, MT = 1 .. 4): the one that minimises (rounds of workgroups over the CUs the launch may use) x (time of one
+// workgroup); one workgroup per CU is resident.  A workgroup's time is NOT proportional to its rows: every workgroup streams the block's
+// whole weight set through its CU (0.75 - 1.25 MB at ~150 GB/s per CU) and pays the dependent chain of phases once, so the model is
+// fixed + rows (fixed = MT_FIXED row tiles' worth; tools/tblock_bench.py at R = 2, T = 500: head 12.2 / 14.2 / 16.8 / 20.6 us and tail
+// 15.6 / 19.0 / 23.1 / 27.3 us for MT = 1 / 2 / 3 / 4, i.e. about 9.4 + 2.8 MT and 11.7 + 3.9 MT).  At the
+// batch-8 shapes (R = 16, T = 1000: 256 or 336 workgroups) it reproduces the r02 choice (64 rows on the whole chip, 48 on 192 CUs);
+// at batch 1 (R = 2) it picks 16-row tiles (126 workgroups instead of 32 on 256 CUs).  p.cus = 0 means the whole chip.
+// CV_TBLOCK_MT=1..4 overrides (tuning aid, read per call: tests switch it).
+constexpr int MT_FIXED = 3;
 int pick_mt(const cv_tblock_params& p) {
-  const int forced = env_int("CV_TBLOCK_MT", 0);   // read per call: tests switch it
-  if (forced == 3 || forced == 4) return forced;
+  const int forced = env_int("CV_TBLOCK_MT", 0);
+  if (forced >= 1 && forced <= 4) return forced;
   const int cus = p.cus > 0 ? p.cus : 256;
-  auto cost = [&](int mt) { const int wgs = p.R * ((p.T + 16 * mt - 1) / (16 * mt)); return (int64_t)((wgs + cus - 1) / cus) * mt; };
-  return cost(3) < cost(4) ? 3 : 4;
+  int best = 4;
+  int64_t best_cost = INT64_MAX;
+  for (int mt = 4; mt >= 1; --mt) {   // ties go to the larger tile (fewer weight re-reads)
+    const int wgs = p.R * ((p.T + 16 * mt - 1) / (16 * mt));
+    const int64_t cost = (int64_t)((wgs + cus - 1) / cus) * (mt + MT_FIXED);
+    if (cost < best_cost) { best_cost = cost; best = mt; }
+  }
+  return best;
 }
 template <int DT>
 void dispatch_head(const cv_tblock_params& p, hipStream_t st) {
@@ -799,8 +825,12 @@ void dispatch_head(const cv_tblock_params& p, hipStream_t st) {
     if (abl == 2) return launch_head<DT, 4, 2>(p, st);
     if (abl == 3) return launch_head<DT, 4, 3>(p, st);
   }
-  if (pick_mt(p) == 3) launch_head<DT, 3, 0>(p, st);
-  else launch_head<DT, 4, 0>(p, st);
+  switch (pick_mt(p)) {
+    case 1: return launch_head<DT, 1, 0>(p, st);
+    case 2: return launch_head<DT, 2, 0>(p, st);
+    case 3: return launch_head<DT, 3, 0>(p, st);
+    default: return launch_head<DT, 4, 0>(p, st);
+  }
 }
 template <int DT, bool OP>
 void dispatch_tail(const cv_tblock_params& p, hipStream_t st) {
@@ -810,8 +840,12 @@ void dispatch_tail(const cv_tblock_params& p, hipStream_t st) {
     if (abl == 2) return launch_tail<DT, OP, 4, 2>(p, st);
     if (abl == 3) return launch_tail<DT, OP, 4, 3>(p, st);
   }
-  if (pick_mt(p) == 3) launch_tail<DT, OP, 3, 0>(p, st);
-  else launch_tail<DT, OP, 4, 0>(p, st);
+  switch (pick_mt(p)) {
+    case 1: return launch_tail<DT, OP, 1, 0>(p, st);
+    case 2: return launch_tail<DT, OP, 2, 0>(p, st);
+    case 3: return launch_tail<DT, OP, 3, 0>(p, st);
+    default: return launch_tail<DT, OP, 4, 0>(p, st);
+  }
 }
 
 }  // namespace
@@ -856,8 +890,8 @@ int launch_resblock(const cv_resblock_params& p, hipStream_t st) {
   const int pitch = ((cinc * 2 + 255) >> 8) << 8, pitch_a = ((p.cin * 2 + 255) >> 8) << 8;
   const size_t lds = (size_t)(16 * MT + 4) * pitch + (STAGE == 2 ? (size_t)16 * MT * pitch_a : 0) + 2 * NW * 64 * 4 + 4096;
   if (lds > 160 * 1024) return CV_ERR_UNSUPPORTED;
-  static size_t attr_lds = 0;
-  if (lds > attr_lds) { set_lds(resblock_kernel<DT, STAGE, MT>, 160 * 1024); attr_lds = 160 * 1024; }
+  static PerDeviceOnce once;
+  once.run([] { set_lds(resblock_kernel<DT, STAGE, MT>, 160 * 1024); });
   dim3 grid((p.T + 16 * MT - 1) / (16 * MT), p.R);
   hipLaunchKernelGGL((resblock_kernel<DT, STAGE, MT>), grid, dim3(NTHR), lds, st, p);
   return hipGetLastError() == hipSuccess ? CV_OK : CV_ERR_LAUNCH;
@@ -866,9 +900,21 @@ template <int STAGE>
 int dispatch_resblock(const cv_resblock_params& p, hipStream_t st) {
   cv_tblock_params q{};   // tile-size choice shared with the transformer-block kernels
   q.R = p.R; q.T = p.T; q.cus = p.cus;
-  const bool mt3 = pick_mt(q) == 3;
-  if (p.dtype == CV_BF16) return mt3 ? launch_resblock<CV_BF16, STAGE, 3>(p, st) : launch_resblock<CV_BF16, STAGE, 4>(p, st);
-  return mt3 ? launch_resblock<CV_F16, STAGE, 3>(p, st) : launch_resblock<CV_F16, STAGE, 4>(p, st);
+  const int mt = pick_mt(q);
+  if (p.dtype == CV_BF16) {
+    switch (mt) {
+      case 1: return launch_resblock<CV_BF16, STAGE, 1>(p, st);
+      case 2: return launch_resblock<CV_BF16, STAGE, 2>(p, st);
+      case 3: return launch_resblock<CV_BF16, STAGE, 3>(p, st);
+      default: return launch_resblock<CV_BF16, STAGE, 4>(p, st);
+    }
+  }
+  switch (mt) {
+    case 1: return launch_resblock<CV_F16, STAGE, 1>(p, st);
+    case 2: return launch_resblock<CV_F16, STAGE, 2>(p, st);
+    case 3: return launch_resblock<CV_F16, STAGE, 3>(p, st);
+    default: return launch_resblock<CV_F16, STAGE, 4>(p, st);
+  }
 }
 int check_resblock(const cv_resblock_params& p, int stage) {
   if (p.dtype != CV_BF16 && p.dtype != CV_F16) return CV_ERR_UNSUPPORTED;

@@ -583,11 +583,8 @@ int launch_ring(const cv_gemm_params& p, hipStream_t st) {
   dim3 grid(mt * nt, 1, p.batch);
   constexpr int STAGES = 3;
   const size_t lds = (size_t)STAGES * 256 * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_ring_kernel<DT, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static PerDeviceOnce once;
+  once.run([&] { hipFuncSetAttribute((const void*)gemm_ring_kernel<DT, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
   hipLaunchKernelGGL((gemm_ring_kernel<DT, STAGES>), grid, dim3(256), lds, st, p);
   CV_CHECK_LAUNCH();
   return CV_OK;

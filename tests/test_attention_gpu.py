@@ -36,8 +36,11 @@ def _ref(q, k, v, scale, klen=None, chunk=0, causal=False, causal_off=0, bias=No
     (2, 8, 8, 500, 500, "plain"), (2, 8, 8, 130, 130, "klen"), (1, 8, 8, 200, 200, "chunk"),
     (2, 14, 2, 107, 107, "causal"), (1, 8, 8, 100, 100, "bias"), (1, 4, 4, 1000, 1000, "plain"),
 ])
-def test_attention_vs_torch(dt, B, H, Hkv, Tq, Tk, mode):
+@pytest.mark.parametrize("waves", ["4", "2"])
+def test_attention_vs_torch(dt, B, H, Hkv, Tq, Tk, mode, waves, monkeypatch):
+    """Both workgroup shapes (128 queries / 4 waves: the batch-8 grids; 64 queries / 2 waves: grids that would not fill the chip)."""
     from cosyvoice_amd import ops
+    monkeypatch.setenv("CV_ATTN_WAVES", waves)
     torch.manual_seed(0)
     dev = "cuda"
     q = torch.randn(B, Tq, H * 64, device=dev).to(dt)

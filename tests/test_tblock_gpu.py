@@ -36,8 +36,10 @@ def _packed(w, dt):
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("R,T", [(2, 150), (1, 64), (3, 1)])
-def test_head_vs_torch(dt, R, T):
+@pytest.mark.parametrize("mt", ["4", "3", "2", "1"])
+def test_head_vs_torch(dt, R, T, mt, monkeypatch):
     from cosyvoice_amd import ops
+    monkeypatch.setenv("CV_TBLOCK_MT", mt)   # rows per workgroup = 16 MT
     w = _weights(dt)
     pk = _packed(w, dt)
     g = torch.Generator().manual_seed(1)
@@ -72,8 +74,10 @@ def _tail_ref(x, ao, w, dt):
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("R,T", [(2, 150), (1, 64), (2, 65)])
 @pytest.mark.parametrize("outproj", [True, False])
-def test_tail_vs_torch(dt, R, T, outproj):
+@pytest.mark.parametrize("mt", ["4", "3", "2", "1"])
+def test_tail_vs_torch(dt, R, T, outproj, mt, monkeypatch):
     from cosyvoice_amd import ops
+    monkeypatch.setenv("CV_TBLOCK_MT", mt)
     w = _weights(dt, seed=2)
     pk = _packed(w, dt)
     g = torch.Generator().manual_seed(3)
@@ -190,7 +194,7 @@ def test_resblock_vs_torch(dt, tol, cin, T):
     p.w2_p, p.b2, p.g2, p.be2 = keep[1].data_ptr(), keep[7].data_ptr(), keep[8].data_ptr(), keep[9].data_ptr()
     p.wr_p, p.br = keep[2].data_ptr(), keep[10].data_ptr()
     p.out, p.ldo, p.eps = outd.data_ptr(), Cc, 1e-5
-    for mt in ("4", "3"):
+    for mt in ("4", "3", "2", "1"):
         os.environ["CV_TBLOCK_MT"] = mt
         h1d.zero_(); outd.zero_()
         ops._issue("cv_resblock_conv1", p)
