@@ -36,6 +36,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 UTT_PER_GPU = 8
+ATTN_PMC = "r03_tblock_hbm.json"            # profiles/: tools/pmc_hbm.py over tools/tblock_bench.py 16 1000
+DECODE_PMC = "r03_roofline_pmc_split_b%d.json"   # profiles/: tools/pmc_hbm.py over tools/roofline_pmc.py <rows> split
+HIFT_PMC = "r03_hift_hbm.json"              # profiles/: tools/pmc_hbm.py over tools/hift_pmc.py
 N_PROMPT, N_GEN, L_TEXT, L_PTEXT = 250, 250, 20, 10
 AUDIO_S_PER_UTT = N_GEN * 2 * 480 / 24000.0  # 10.0 s
 
@@ -69,12 +72,16 @@ def cpu_model_string():
 
 def cpu_baseline(lsd, fsd, hsd, lc, fc, hc):
     """The oracle (CPU port of the reference arithmetic) timed on this host's cores on a bounded sample of the SAME workload:
-    every component is run once to warm (thread pool, allocator, page faults) and then three times, the MEDIAN is kept, and the
-    per-utterance time is extrapolated linearly in the repeated units (decode steps, Euler steps, mel frames)."""
+    every component is run once to warm (thread pool, allocator, page faults) and then timed (median of 3 for C4, of 2 for C1), and the
+    per-utterance time is EXTRAPOLATED linearly in the repeated units (decode steps, Euler steps, mel frames) — `kind` says so.
+    Two workloads: the headline's (C4 utterance: 10 s prompt, prefill 282, flow T = 1000) and BASELINE config C1 (3 s prompt + 20-token
+    text: prefill 107, flow T = 650), the reference's own CPU-runnable case."""
     from oracle import flow as of
     from oracle import hift as oh
     from oracle import llm as ol
-    # the GPU box gives one GPU a 16-core CPU share; torch's default (all hardware threads) is far slower on these small ops
+    # cores: the GPU box leases one GPU together with a 16-core share of the host CPU (gpurun's process guard sizes worker pools to
+    # it; the driver runs 8 ranks per node, 8 x 16 = the host's 128 hardware threads), so 16 threads is "all the cores this GPU's
+    # process may use".  torch's default (every hardware thread of the host) also runs these small ops slower.
     cores = min(16, torch.get_num_threads())
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(1)
@@ -88,8 +95,8 @@ def cpu_baseline(lsd, fsd, hsd, lc, fc, hc):
             ts.append(time.perf_counter() - t0)
         return statistics.median(ts)
 
-    with torch.inference_mode():
-        L = 1 + L_PTEXT + L_TEXT + 1 + N_PROMPT
+    def sample(n_prompt, reps):
+        L = 1 + L_PTEXT + L_TEXT + 1 + n_prompt
         x = torch.randn(1, L, lc.hidden_size, generator=g) * 0.02
         x1 = torch.randn(1, 1, lc.hidden_size, generator=g) * 0.02
 
@@ -98,33 +105,47 @@ def cpu_baseline(lsd, fsd, hsd, lc, fc, hc):
             y = ol.qwen2_forward(lsd, lc, x, cache)
             ol.logits_to_logp(lsd, y[:, -1])
             return cache
-        t_pre = med(prefill)
+        t_pre = med(prefill, reps)
         cache = prefill()
 
-        def step4():   # 4 decode steps at context ~ 282..294 (the cache grows by 4 per call: 16 steps in all)
+        def step4():   # 4 decode steps from context L on (the cache grows by 4 per call)
             for _ in range(4):
                 y = ol.qwen2_forward(lsd, lc, x1, cache)
                 ol.logits_to_logp(lsd, y[:, -1])
-        t_step = med(step4) / 4
-        N = N_PROMPT + N_GEN
+        t_step = med(step4, reps) / 4
+        N = n_prompt + N_GEN
         xs = torch.randn(1, N, fc.input_size, generator=g)
-        t_enc = med(lambda: of.encoder_forward(fsd, fc, xs, torch.tensor([N]), 0))
+        t_enc = med(lambda: of.encoder_forward(fsd, fc, xs, torch.tensor([N]), 0), reps)
         T = 2 * N
         a = lambda *s: torch.randn(*s, generator=g)
         ex = (a(2, 80, T), torch.ones(2, 1, T), a(2, 80, T), torch.tensor([0.5, 0.5]), a(2, 80), a(2, 80, T))
-        t_est = med(lambda: of.estimator_forward(fsd, fc, *ex))
-        mel = torch.clamp(a(1, 80, 100) * 2 - 6, -11.5, 2.0)
+        t_est = med(lambda: of.estimator_forward(fsd, fc, *ex), reps)
+        return L, N, T, t_pre, t_step, t_enc, t_est
+
+    with torch.inference_mode():
+        L, N, T, t_pre, t_step, t_enc, t_est = sample(N_PROMPT, 3)
+        mel = torch.clamp(torch.randn(1, 80, 100, generator=g) * 2 - 6, -11.5, 2.0)
         ph, nz = oh.draw_source_randoms(hc, 1, 100 * hc.total_upsample, seed=2)
         t_hift = med(lambda: oh.inference(hsd, hc, mel, None, ph, nz)) * 5
+        c1 = sample(75, 2)
     t_dec = (N_GEN - 1) * t_step
     per_utt = t_pre + t_dec + t_enc + fc.n_timesteps * t_est + t_hift
-    return {"value": round(AUDIO_S_PER_UTT / per_utt, 4), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
+    L1, N1, T1, p1, s1, e1, est1 = c1
+    per_utt_c1 = p1 + (N_GEN - 1) * s1 + e1 + fc.n_timesteps * est1 + t_hift
+    return {"value": round(AUDIO_S_PER_UTT / per_utt, 4), "unit": "audio-seconds/sec", "cores": cores, "kind": "port, extrapolated sample",
+            "cores_note": "16 = the CPU share the GPU box leases with one GPU (8 ranks x 16 threads = the host's 128 hardware threads)",
             "cpu_model": cpu_model_string(),
             "stages_s": {"llm_prefill": round(t_pre, 3), "llm_decode": round(t_dec, 3), "flow_encoder": round(t_enc, 3),
                          "flow_solver": round(fc.n_timesteps * t_est, 3), "hift": round(t_hift, 3), "per_utterance": round(per_utt, 2)},
-            "sample": (f"oracle fp32, 1 utterance of the same workload, every component warmed once then median of 3: prefill L=282 "
-                       f"({t_pre:.2f}s) + 4 decode steps ({t_step*1e3:.1f} ms/step, x249) + flow encoder N=500 ({t_enc:.2f}s) + 1 estimator "
-                       f"call T=1000 ({t_est:.2f}s, x10) + HiFT 100/500 frames (x5 = {t_hift:.2f}s)")}
+            "sample": (f"oracle fp32, 1 utterance of the same workload, every component warmed once then median of 3: prefill L={L} "
+                       f"({t_pre:.2f}s) + 4 decode steps ({t_step*1e3:.1f} ms/step, x249) + flow encoder N={N} ({t_enc:.2f}s) + 1 estimator "
+                       f"call T={T} ({t_est:.2f}s, x10) + HiFT 100/500 frames (x5 = {t_hift:.2f}s)"),
+            "c1": {"workload": "BASELINE C1: zero-shot, 3 s prompt (75 tokens, 150 mel frames) + 20-token text -> 250 tokens = 10 s of audio; CPU fp32",
+                   "value": round(AUDIO_S_PER_UTT / per_utt_c1, 4), "unit": "audio-seconds/sec", "rtf": round(per_utt_c1 / AUDIO_S_PER_UTT, 3),
+                   "stages_s": {"llm_prefill": round(p1, 3), "llm_decode": round((N_GEN - 1) * s1, 3), "flow_encoder": round(e1, 3),
+                                "flow_solver": round(fc.n_timesteps * est1, 3), "hift": round(t_hift, 3), "per_utterance": round(per_utt_c1, 2)},
+                   "sample": (f"same method, median of 2: prefill L={L1} ({p1:.2f}s) + 4 decode steps ({s1*1e3:.1f} ms/step, x249) + flow encoder "
+                              f"N={N1} ({e1:.2f}s) + 1 estimator call T={T1} ({est1:.2f}s, x10) + the HiFT sample above")}}
 
 
 def ev_time(fn, n, warm=2):
@@ -212,26 +233,54 @@ def main():
     B = len(mine)
     texts_d = [texts[i].to(dev) for i in mine]
     forced_m = [forced[i] for i in mine]
-    # conditioning payload [prompt mel | speaker embedding | prompt speech tokens | prompt text ids], one flat fp32 buffer
-    payload, layout = cd.pack_conditioning(pfeat, emb, pspeech, ptext)
-    cond_buf = payload.to(dev) if rank == 0 else torch.zeros_like(payload).to(dev)   # only rank 0 holds it before the broadcast
+    # conditioning payload [prompt mel | speaker embedding | prompt speech tokens | prompt text ids], one flat fp32 buffer PER BATCH:
+    # every pipeline pass has its own speaker prompt (a perturbed prompt mel / embedding, its own prompt speech tokens), so a payload
+    # that reached a consumer late, early or overwritten would change that pass's audio.  Rank 0 holds all of them in HBM before the
+    # timed region; the other ranks only ever see what the per-batch broadcast delivers.
+    n_payloads = args.warmup + args.steps + 8
+    _, layout = cd.pack_conditioning(pfeat, emb, pspeech, ptext)
 
-    def bcast():
-        cd.broadcast_conditioning(cond_buf, dist, src=0)
+    def payload_of(i):
+        g = torch.Generator().manual_seed(7000 + i)
+        pf = torch.clamp(pfeat + 0.05 * torch.randn(pfeat.shape, generator=g), -11.5, 2.0)
+        em = emb + 0.1 * torch.randn(emb.shape, generator=g)
+        ps = torch.randint(0, lc.speech_token_size, pspeech.shape, generator=g, dtype=torch.int32)
+        return cd.pack_conditioning(pf, em, ps, ptext)[0]
+    payloads = [payload_of(i).to(dev) for i in range(n_payloads)] if rank == 0 else None
+    # one slot per batch in flight (cosyvoice_amd.dist.ConditioningRing): held from the batch's broadcast until tts_batches reports
+    # the batch done, so a later broadcast never rewrites conditioning a running decode / flow job still reads
+    merge = max(1, args.llm_merge)
+    ring = cd.ConditioningRing((max(1, args.llm_loops) + 2) * merge + merge + 2, layout, dev)
+    seq = {"i": 0}
 
-    def make_batch():
-        pf, em, ps, pt = cd.unpack_conditioning(cond_buf, layout)
+    def make_batch(local=False):
+        """``local``: rank 0 fills the slot itself, no collective (the single-rank measurements after the timed region)."""
+        i = seq["i"] % n_payloads
+        seq["i"] += 1
+        slot = ring.acquire()
+        buf = ring.slots[slot]
+
+        def bcast():
+            if rank == 0:
+                buf.copy_(payloads[i])
+            cd.broadcast_conditioning(buf, dist, src=0)
+            ring.after_broadcast(slot)   # token ids -> the slot's int32 tensors, stream-ordered behind the broadcast
+        pf, em, ps, pt = ring.tensors(slot)
+        if local:
+            buf.copy_(payloads[i])
+            ring.after_broadcast(slot)
         return dict(texts=texts_d, prompt_texts=[pt] * B, llm_prompt_speech_tokens=[ps] * B,
                     flow_prompt_speech_tokens=ps.expand(B, -1), prompt_speech_feats=pf.expand(B, -1, -1),
-                    flow_embeddings=em.expand(B, -1), forced=forced_m, on_start=bcast)
+                    flow_embeddings=em.expand(B, -1), forced=forced_m, on_start=bcast, on_done=lambda: ring.release(slot))
 
     def run_steps(n):
         """n pipeline passes ("steps", one batch of 8 utterances each): the decode loops of later passes (two at a time, on
         their CU share) overlap flow + HiFT of pass i (on the other CUs); every waveform is copied to the host inside the
-        region."""
+        region.  Batches are made lazily: a pass takes its conditioning slot when the pipeline admits it."""
         last = None
-        for wav in model.tts_batches([make_batch() for _ in range(n)], to_host=True, llm_cu_slots=args.llm_cu_slots, llm_loops=args.llm_loops):
+        for wav in model.tts_batches((make_batch() for _ in range(n)), to_host=True, llm_cu_slots=args.llm_cu_slots, llm_loops=args.llm_loops):
             last = wav
+        assert ring.in_use() == 0
         return last
 
     def fence():
@@ -239,7 +288,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    bcast()   # the payload is in place on every rank before the first batch is assembled
     if args.warmup > 0:
         w = run_steps(args.warmup)
         log(f"[rank {rank}] warmup: wav {tuple(w.shape)} absmax {w.abs().max().item():.3f}")
@@ -268,7 +316,7 @@ def main():
 
     out = None
     if rank == 0:
-        one = make_batch()
+        one = make_batch(local=True)
         # ---- batch-1 latency of the same pipeline (BASELINE metric: "batch 1 and 8"; north_star target RTF < 0.05)
         def run1():
             return model.tts_batch(one["texts"][:1], one["prompt_texts"][:1], one["llm_prompt_speech_tokens"][:1],
@@ -366,6 +414,25 @@ def measure_extras(model, llm, flow, hift, lc, fc, hc, one, forced_m, fdt, args)
                          "us_per_step": round(step_s * 1e6, 1), "achieved": round(step_bytes / step_s / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(step_bytes / step_s / 8e12, 4)}
     res["roofline_decode"] = dec
+    # ---------------- C1 on the GPU: zero-shot, 3 s prompt (75 prompt tokens / 150 prompt frames) + 20-token text, one utterance end to end
+    # (prefill 107 -> 250 tokens, flow T = 650, HiFT 500 frames, waveform on the host); RTF as the reference logs it (cli/cosyvoice.py:73-74)
+    n3 = 75
+    c1a = (one["texts"][:1], one["prompt_texts"][:1], [one["llm_prompt_speech_tokens"][0][:, :n3]], one["flow_prompt_speech_tokens"][:1, :n3],
+           one["prompt_speech_feats"][:1, :2 * n3], one["flow_embeddings"][:1])
+    run_c1 = lambda: model.tts_batch(*c1a, forced=forced_m[:1], to_host=True)
+    for _ in range(2):
+        run_c1()
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        w1 = run_c1()
+        ts.append(time.perf_counter() - t0)
+    lat_c1 = statistics.median(ts)
+    res["c1_zero_shot_3s_prompt"] = {"workload": "BASELINE C1 on 1 x MI355X: zero-shot, 3 s prompt + 20-token text, 1 utterance, prefill 107, 250 tokens, "
+                                                 "flow T = 650, HiFT 500 frames -> 10 s of audio on the host",
+                                     "latency_ms": round(lat_c1 * 1e3, 2), "rtf": round(lat_c1 / AUDIO_S_PER_UTT, 5),
+                                     "audio_s_per_s": round(AUDIO_S_PER_UTT / lat_c1, 2), "samples": int(w1.shape[-1])}
     # ---------------- C2: flow-matching decoder only, one utterance, 80 mel x 500 frames, 10 Euler steps
     tok1 = tok[:1]
     ptok0 = torch.zeros(1, 0, dtype=torch.int32, device=dev)
@@ -375,8 +442,8 @@ def measure_extras(model, llm, flow, hift, lc, fc, hc, one, forced_m, fdt, args)
     res["c2_flow_only"] = {"workload": "C2: flow-matching decoder only, 1 utterance, 250 tokens -> 80 mel x 500 frames, encoder + 10 CFG Euler steps",
                            "dtype": str(fdt).replace("torch.", ""), "ms": round(t_c2 * 1e3, 2), "tflops": round(1.895 / t_c2, 1),
                            "frac_of_2.5PF": round(1.895 / t_c2 / 2500.0, 4),
-                           "note": "batch 1: ~6 000 dependent launches in one hipGraph, launch-latency bound; bf16 operands miss the 1e-3 mel "
-                                   "target (DESIGN.md §2), so the bench default is fp16"}
+                           "note": "batch 1: ~4 700 dependent launches in one hipGraph (16-row tiles, 64-query attention workgroups: 126 - 128 workgroups "
+                                   "per launch), each ~10 us of dependent chain; bf16 operands miss the 1e-3 mel target (DESIGN.md §2), so the bench default is fp16"}
     # ---------------- C3: HiFT only, v1 22.05 kHz generator, 10 s of mel (861 frames -> 220 416 samples)
     hc1 = HiftConfig.v1()
     hsd1 = hift_state_dict(hc1)
@@ -392,7 +459,47 @@ def measure_extras(model, llm, flow, hift, lc, fc, hc, one, forced_m, fdt, args)
                     "mfma_tflops_issued": round(mf, 1), "mfma_frac": round(mf / (2500.0 if mode == "bf16x3" else 157.3), 4)}
         del h1
     res["c3_hift_only"] = c3
+    # ---------------- HiFT roofline (BASELINE C3 asks for the HBM roofline): the pipeline's own vocoder (v2, 24 kHz), one utterance of 500 frames
+    mel_1 = mel[:1].contiguous()
+    src_1 = torch.zeros(1, 1, mel_1.shape[2] * hc.total_upsample, device=dev)
+    t_h1 = ev_time(lambda: hift.decode(mel_1, src_1), 8, warm=3)
+    comp = (385.8e6 + 20.82e6) * 4      # sum over convs of (in + out) elements + parameters, fp32
+    total, tsrc = None, {"status": "no usable profile"}
+    try:
+        import hashlib
+        d = json.load(open(os.path.join(ROOT, "profiles", HIFT_PMC)))
+        ok = all(hashlib.sha256(open(os.path.join(ROOT, "cosyvoice_amd", "csrc", f), "rb").read()).hexdigest() == h for f, h in d["source_sha256"].items())
+        tsrc = {"file": "profiles/" + HIFT_PMC, "measured_live": False, "collected_at": d.get("git_head_at_collection"), "units": d.get("units"),
+                "status": "current" if ok else "stale: the profile was collected on a different version of the kernel sources"}
+        if ok and d.get("units"):
+            total = int(d["total_hbm_bytes"] / d["units"])
+    except Exception as e:
+        tsrc = {"status": f"no usable profile ({type(e).__name__})"}
+    res["roofline_hift"] = {"bound": "hbm", "what": "HiFTGenerator.decode, v2 24 kHz, 1 utterance x 500 frames -> 240 000 samples, fp32 tensors, bf16x3 products (~100 conv launches)",
+                            "achieved": round(comp / t_h1 / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(comp / t_h1 / 8e12, 4),
+                            "compulsory_bytes": comp, "traffic": total, "traffic_source": tsrc, "ms": round(t_h1 * 1e3, 3),
+                            "mfma_tflops_issued": round(3 * 306.15e9 / t_h1 / 1e12, 1), "mfma_frac": round(3 * 306.15e9 / t_h1 / 2.5e15, 4),
+                            "note": "the decode is MFMA-issue / latency bound, not HBM bound: at 8 TB/s the compulsory 1.63 GB take 0.2 ms"}
     return res
+
+
+def pmc_traffic(fname, kernel_substr, src):
+    """HBM bytes per launch of a kernel from a committed pair of rocprofv3 --pmc passes (tools/pmc_hbm.py) — REPLAYED from the
+    profile, not measured by this run, and only when the profile was collected on the kernel source this run is using (the JSON
+    records the file's SHA-256).  Returns (bytes or None, provenance dict)."""
+    import hashlib
+    info = {"file": "profiles/" + fname, "kernel_source": "cosyvoice_amd/csrc/" + src, "measured_live": False}
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", fname)))
+        want = hashlib.sha256(open(os.path.join(ROOT, "cosyvoice_amd", "csrc", src), "rb").read()).hexdigest()
+    except Exception as e:
+        return None, dict(info, status=f"no usable profile ({type(e).__name__})")
+    if d.get("source_sha256", {}).get(src) != want:
+        return None, dict(info, status="stale: the profile was collected on a different version of the kernel source", collected_at=d.get("git_head_at_collection"))
+    for k, v in d.get("kernels", {}).items():
+        if kernel_substr in k:
+            return v["hbm_bytes_per_launch"], dict(info, status="current", kernel=k, launches=v["launches"], collected_at=d.get("git_head_at_collection"))
+    return None, dict(info, status="kernel not in the profile")
 
 
 def measure_attention_roofline(flow, B):
@@ -414,16 +521,12 @@ def measure_attention_roofline(flow, B):
     dur = ev_time(g.launch, 5, warm=2) / n
     g.destroy()
     flops = 4.0 * R * H * T * T * 64
-    traffic, alg_bytes = None, 4 * R * T * H * 64 * 2   # Q, K, V^T read + O written once, 16-bit
-    pmc = os.path.join(ROOT, "profiles", "r02_f_tblock_hbm.json")   # separate --pmc FETCH_SIZE / WRITE_SIZE passes at this shape (R = 16, T = 1000)
-    if os.path.exists(pmc) and (R, T) == (16, 1000):
-        try:
-            traffic = json.load(open(pmc))["kernels"]["attn_kernel<2>"]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
-    return {"bound": "mfma", "kernel": f"attn_kernel<f16> (flow estimator flash attention, {R} rows x {H} heads x T={T}, head_dim 64)",
+    alg_bytes = 4 * R * T * H * 64 * 2   # Q, K, V^T read + O written once, 16-bit
+    # separate --pmc FETCH_SIZE / WRITE_SIZE passes over tools/tblock_bench.py at this shape (R = 16, T = 1000)
+    traffic, tsrc = pmc_traffic(ATTN_PMC, "attn_kernel<2, 4>", "attention.hip") if (R, T) == (16, 1000) else (None, {"status": "no profile for this shape"})
+    return {"bound": "mfma", "kernel": f"attn_kernel<f16, 4 waves> (flow estimator flash attention, {R} rows x {H} heads x T={T}, head_dim 64)",
             "achieved": round(flops / dur / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(flops / dur / 2.5e15, 4),
-            "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "flops_per_launch": flops, "avg_launch_us": round(dur * 1e6, 2),
+            "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": alg_bytes, "flops_per_launch": flops, "avg_launch_us": round(dur * 1e6, 2),
             "note": "algorithmic flops per launch = 4 R H T^2 d (QK^T and PV), SURVEY.md §8d's 2048 T flop per row per block; traffic = HBM bytes per "
                     "launch from PMC (2 x FETCH_SIZE + WRITE_SIZE): every (row, head)'s K / V^T is fetched once (one XCD per head)"}
 
@@ -455,20 +558,12 @@ def measure_decode_roofline(llm, lc, rows=UTT_PER_GPU):
         alg = 2 * I * H * 2 + B * H * 2 + npart * (16 if B <= 16 else 32) * 4 + B * I * 2   # packed bf16 weights + bf16 rows + partial sums + bf16 SwiGLU out
     else:
         alg = 2 * I * H * 2 + B * H * 4 + H * 4 + B * I * 2   # packed bf16 weights + fp32 residual rows + gamma + bf16 SwiGLU out
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", ("r01_roofline_pmc_split_b%d.json" % B) if split else
-                       ("r01_roofline_pmc.json" if B <= 8 else "r01_roofline_pmc_b16.json"))
-    if split and os.path.exists(os.path.join(ROOT, "profiles", "r02_roofline_pmc_split_b%d.json" % B)):
-        pmc = os.path.join(ROOT, "profiles", "r02_roofline_pmc_split_b%d.json" % B)
-    if os.path.exists(pmc):  # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/roofline_pmc.py)
-        try:
-            traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+    # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/roofline_pmc.py <rows> split
+    traffic, tsrc = pmc_traffic(DECODE_PMC % B, "skinny_kernel<", "llm.hip") if split else (None, {"status": "no profile for the fused-prologue form"})
     return {"bound": "hbm", "kernel": (f"skinny_kernel<{'f16' if llm.dtype == torch.float16 else 'bf16'},TPW=2,no prologue,U=7,RS{',MR=2' if B > 16 else ''}> (decode gate/up, split RMSNorm: 1/rms in the epilogue, + SwiGLU), {B} rows" if split else
                        f"skinny_kernel<{'f16' if llm.dtype == torch.float16 else 'bf16'},TPW=2,norm,TPR={32 if B <= 8 else 16},U=7> (decode gate/up + RMSNorm prologue + SwiGLU), {B} rows"),
             "achieved": round(alg / dur / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(alg / dur / 8e12, 4),
-            "traffic": traffic, "bytes_per_launch": alg, "avg_launch_us": round(dur * 1e6, 3)}
+            "traffic": traffic, "traffic_source": tsrc, "bytes_per_launch": alg, "avg_launch_us": round(dur * 1e6, 3)}
 
 
 if __name__ == "__main__":

@@ -233,6 +233,8 @@ extern "C" int cv_to_channels_first(const float* x, float* out, int32_t B, int32
 extern "C" int cv_snake_multi(const float* x, int32_t rows, int32_t C, int32_t ldx, int32_t n, const float* const* alpha,
                               void* const* out, int32_t ldo, int32_t dtype, void* stream) {
   if (!x || rows <= 0 || C <= 0 || (C & 3) || (ldx & 3) || (ldo & 3) || n < 1 || n > 4 || !alpha || !out) return CV_ERR_ARG;
+  // pre-split output: whole groups of 8 values ([8 hi | 8 lo], 32 bytes) — a half group at a row's end would put its lo half past the row
+  if (dtype == CV_F32X3 && ((C & 7) || (ldo & 7))) return CV_ERR_ARG;
   SnakeArgs a{};
   for (int i = 0; i < n; ++i) { a.alpha[i] = alpha[i]; a.out[i] = out[i]; if (!alpha[i] || !out[i]) return CV_ERR_ARG; }
   const int64_t n4 = (int64_t)rows * (C >> 2);

@@ -372,7 +372,11 @@ int check_hift_desc(const cv_hift_decode_desc* d) {
         !g.out || !g.source_rb.units || g.source_rb.n_units <= 0 || g.t_out <= 0 || g.c <= 0) return CV_ERR_ARG;
     for (int j = 0; j < d->n_kernels; ++j)
       if (!g.rbs[j].units || g.rbs[j].n_units <= 0 || !g.xa[j]) return CV_ERR_ARG;
+    // pre-split activation storage ([8 hi | 8 lo] groups of 8 values): every channel count it is applied to is a whole number of groups
+    const bool any_x3 = d->presplit || g.up_flags || g.source_down.x3_flags;
+    if (any_x3 && (g.c & 7)) return CV_ERR_ARG;
   }
+  if ((d->presplit || d->conv_pre.x3_flags) && (d->conv_pre.cout & 7)) return CV_ERR_ARG;
   return CV_OK;
 }
 }  // namespace

@@ -82,7 +82,14 @@ class UpsampleConformerEncoder:
         return dict(w=P.w(f"{name}.out.0.weight"), b=P.f32(f"{name}.out.0.bias"), g=P.f32(f"{name}.out.1.weight"),
                     beta=P.f32(f"{name}.out.1.bias"))
 
+    def _invalidate(self):
+        """Called by every load(): the projected position tables are products of the layers' linear_pos weights."""
+        if self._pos:
+            torch.cuda.synchronize()
+            self._pos.clear()
+
     def load(self, sd, prefix="encoder."):
+        self._invalidate()
         cfg = self.cfg
         P = _P(sd, self.dtype, self.device)
         D = cfg.enc_dim
@@ -271,6 +278,9 @@ class ConditionalDecoder:
         self.tm_b = torch.cat([sd[f"{n}.0.mlp.1.bias"].float() for n in names], 0).to(device=self.device).contiguous()
 
     def load(self, sd, prefix="decoder.estimator."):
+        if self._tcache:   # time embeddings through the time_mlp weights replaced below
+            torch.cuda.synchronize()
+            self._tcache.clear()
         cfg = self.cfg
         P = _P(sd, self.dtype, self.device)
         self.P = P
@@ -617,6 +627,7 @@ class CausalMaskedDiffWithXvec:
         return self
 
     def load_state_dict(self, sd, strict: bool = False):
+        ops.drop_graphs(self.decoder._graphs)   # captured Euler loops hold raw pointers of the estimator weights replaced below
         sd = {k: v.detach().to("cpu") for k, v in sd.items()}
         P = _P(sd, self.dtype, self.device)
         self.emb_table = P.f32("input_embedding.weight")

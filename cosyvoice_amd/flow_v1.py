@@ -25,6 +25,9 @@ class ConditionalDecoderV1(ConditionalDecoder):
     fused_all = False   # GroupNorm resnets, strided down / transposed up convs: not what cv_flow_euler_* composes
 
     def load(self, sd, prefix="decoder.estimator."):
+        if self._tcache:   # time embeddings through the time_mlp weights replaced below
+            torch.cuda.synchronize()
+            self._tcache.clear()
         cfg = self.cfg
         P = _P(sd, self.dtype, self.device)
         names = ([f"{prefix}down_blocks.0", f"{prefix}down_blocks.1"] + [f"{prefix}mid_blocks.{i}" for i in range(cfg.est_mid_blocks)]
@@ -156,6 +159,7 @@ class MaskedDiffWithXvec:
         return self
 
     def load_state_dict(self, sd, strict: bool = False):
+        ops.drop_graphs(self.decoder._graphs)   # captured Euler loops hold raw pointers of the estimator weights replaced below
         sd = {k: v.detach().to("cpu") for k, v in sd.items()}
         cfg = self.cfg
         P = _P(sd, self.dtype, self.device)

@@ -104,6 +104,11 @@ class HiFTGenerator:
         return self
 
     def load_state_dict(self, sd, strict: bool = False):
+        # per-shape workspaces cache the decode descriptor (raw pointers of every conv / phase / alpha tensor): a reload replaces
+        # those tensors, so everything derived from the old ones goes first
+        if self._ws:
+            torch.cuda.synchronize()
+            self._ws.clear()
         sd = {k.replace("generator.", ""): v.detach().to("cpu", torch.float32) for k, v in sd.items()}  # model.py:79
         cfg, dt, dev = self.cfg, self.dtype, self.device
         f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()

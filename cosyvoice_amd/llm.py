@@ -72,6 +72,7 @@ class Qwen2LM:
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd, strict: bool = False):
+        ops.drop_graphs(self._graphs)   # captured decode steps hold raw pointers of the weights / state buffers replaced below
         cfg, dt, dev = self.cfg, self.dtype, self.device
         f32 = lambda k: sd[k].detach().to(device=dev, dtype=torch.float32).contiguous()
         w16 = lambda t: t.detach().to(torch.float32).to(device=dev, dtype=dt).contiguous()

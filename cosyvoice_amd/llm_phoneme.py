@@ -29,6 +29,7 @@ class _TextEncoder(UpsampleConformerEncoder):
         assert pcfg.enc_dim // pcfg.enc_heads == 64, "the attention kernel is built for 64-wide heads"
 
     def load(self, sd, prefix="text_encoder."):
+        self._invalidate()
         P = _P(sd, self.dtype, self.device)
         self.embed = self._load_embed(P, prefix + "embed")
         self.layers = [self._load_layer(P, sd, f"{prefix}encoders.{i}") for i in range(self.cfg.enc_blocks)]

@@ -36,6 +36,7 @@ class _CausalStack(UpsampleConformerEncoder):
         assert cfg.llm_dim // cfg.llm_heads == 64, "the attention kernel is built for 64-wide heads"
 
     def load(self, sd, prefix="llm."):
+        self._invalidate()
         P = _P(sd, self.dtype, self.device)
         self.embed = self._load_embed(P, prefix + "embed")
         self.layers = [self._load_layer(P, sd, f"{prefix}encoders.{i}", "norm1", "norm2") for i in range(self.cfg.enc_blocks)]

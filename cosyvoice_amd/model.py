@@ -10,6 +10,7 @@ The stage objects are the HIP-backed ``cosyvoice_amd.llm.Qwen2LM`` / ``flow.Caus
 sequences, flow batched over B CFG pairs, HiFT batched over B mels.
 """
 import os
+import collections
 import threading
 import time
 import uuid
@@ -73,7 +74,8 @@ class CosyVoice2Model:
         self.tts_speech_token_dict = {}
         self.llm_end_dict = {}
         self.hift_cache_dict = {}
-        self._llm_spans = {}      # uuid -> [start, end] wall-clock of the request's token loop (diagnostics / tests)
+        self._llm_spans = collections.OrderedDict()   # uuid -> [start, end] wall-clock of the request's token loop (diagnostics / tests); the last 64 requests
+        self._llm_errors = {}     # uuid -> exception raised inside the request's LLM thread; tts() re-raises it in the caller
         self.overlap_hift = os.environ.get("CV_OVERLAP_HIFT", "0") != "0"   # tts_batches: HiFT of batch i on its own stream beside flow of batch i + 1 (measured SLOWER: 455 vs 548 audio-s/s — the vocoder GEMMs and the flow chain disturb each other on shared CUs; kept for experiments)
         # tts_batches: where the decode jobs' prefills run.  True = on the flow CUs (throughput-bound GEMM work over B x 282 rows); False = on
         # the decode CUs with the token loop.  Re-checked in round 2, when the flow + HiFT stream became the bottleneck: still better on the
@@ -81,25 +83,39 @@ class CosyVoice2Model:
         self.prefill_on_flow_cus = os.environ.get("CV_PREFILL_ON_FLOW", "1") != "0"
         self.pipeline_stats = None  # set to a list to collect (stage, batches, start, end) of every tts_batches job
 
+    def _drop_contexts(self):
+        """Forget every extra decode context (they share the weight tensors of the LM they were made from: after a reload they
+        would keep decoding with the old weights) and their captured graphs."""
+        from . import ops
+        with self._req_pool_lock:
+            ctxs = [c for c, _ in (self._req_pool or [])] + [c for c in (getattr(self, "_llm_contexts", None) or []) if c is not self.llm]
+            for c in ctxs:
+                ops.drop_graphs(getattr(c, "_graphs", {}))
+            self._req_pool, self._req_made = None, 0
+            self._llm_contexts = None
+
     def load(self, llm_model, flow_model, hift_model):
         """model.py:71-81 — three flat state-dict files with the reference key names."""
+        self._drop_contexts()
         self.llm.load_state_dict(torch.load(llm_model, map_location="cpu", weights_only=True), strict=False)
         self.flow.load_state_dict(torch.load(flow_model, map_location="cpu", weights_only=True), strict=False)
         hift_sd = {k.replace("generator.", ""): v for k, v in torch.load(hift_model, map_location="cpu", weights_only=True).items()}
         self.hift.load_state_dict(hift_sd, strict=False)
 
     def load_state_dicts(self, llm_sd, flow_sd, hift_sd):
+        self._drop_contexts()
         self.llm.load_state_dict(llm_sd)
         self.flow.load_state_dict(flow_sd)
         self.hift.load_state_dict(hift_sd)
         return self
 
     def _acquire_llm(self):
-        """A free (decode context, stream) pair for one request; grows the pool up to max_llm_requests, then waits."""
+        """A free (decode context, stream) pair for one request; grows the pool up to max_llm_requests, then waits.  Every pooled
+        context is a Qwen2LM.new_context(): ``self.llm`` itself stays reserved for the batch paths (tts_batch / tts_batches use it
+        without taking the pool), so a tts() request never shares KV caches or device state with a running batch."""
         with self._req_pool_lock:
             if self._req_pool is None:
-                self._req_pool = [(self.llm, self.llm_context.stream if hasattr(self.llm_context, "stream") else torch.cuda.Stream(self.device, priority=-1))]
-                self._req_made = 1
+                self._req_pool, self._req_made = [], 0
             while True:
                 if self._req_pool:
                     return self._req_pool.pop()
@@ -128,23 +144,31 @@ class CosyVoice2Model:
         kw = dict(text=text_a, text_len=text_len, prompt_text=ptext_a, prompt_text_len=ptext_len,
                   prompt_speech_token=llm_prompt_speech_token.to(self.device),
                   prompt_speech_token_len=torch.tensor([llm_prompt_speech_token.shape[1]], dtype=torch.int32), embedding=llm_embedding)
-        if hasattr(self.llm, "new_context"):
-            pair = self._acquire_llm()
-            try:
-                ctx, stream = pair
-                self._llm_spans[uuid_] = [time.perf_counter(), None]
-                with torch.cuda.stream(stream):
-                    for i in ctx.inference(nonce=seed, **kw):
+        try:
+            if hasattr(self.llm, "new_context"):
+                pair = self._acquire_llm()
+                try:
+                    ctx, stream = pair
+                    with self.lock:
+                        self._llm_spans[uuid_] = [time.perf_counter(), None]
+                        while len(self._llm_spans) > 64:
+                            self._llm_spans.popitem(last=False)
+                    span = self._llm_spans[uuid_]
+                    with torch.cuda.stream(stream):
+                        for i in ctx.inference(nonce=seed, **kw):
+                            self.tts_speech_token_dict[uuid_].append(i)
+                        stream.synchronize()
+                    span[1] = time.perf_counter()
+                finally:
+                    self._release_llm(pair)
+            else:
+                with self.llm_lock, self.llm_context:
+                    for i in self.llm.inference(**kw):
                         self.tts_speech_token_dict[uuid_].append(i)
-                    stream.synchronize()
-                self._llm_spans[uuid_][1] = time.perf_counter()
-            finally:
-                self._release_llm(pair)
-        else:
-            with self.llm_lock, self.llm_context:
-                for i in self.llm.inference(**kw):
-                    self.tts_speech_token_dict[uuid_].append(i)
-        self.llm_end_dict[uuid_] = True
+        except BaseException as e:      # the consumer loop of tts() polls llm_end_dict: it must see the end, and the error
+            self._llm_errors[uuid_] = e
+        finally:
+            self.llm_end_dict[uuid_] = True
 
     def token2wav(self, *args, **kwargs):
         """Reference signature (model.py:334 / :130 for the v1 wiring); one call at a time per model object (flow_lock)."""
@@ -197,35 +221,47 @@ class CosyVoice2Model:
         # torch's global generator (as the reference samples from the global RNG), an int makes the request reproducible
         p = threading.Thread(target=self.llm_job, args=(text, prompt_text, llm_prompt_speech_token, llm_embedding, this_uuid, kwargs.get("seed")))
         p.start()
-        if stream is True:
-            self.flow.length_bucket = self.stream_length_bucket
-            token_offset = 0
-            need = self.token_hop_len + self.flow.pre_lookahead_len
-            while True:
-                time.sleep(0.02)
-                if len(self.tts_speech_token_dict[this_uuid]) - token_offset >= need:
-                    this_tok = torch.tensor(self.tts_speech_token_dict[this_uuid][:token_offset + need]).unsqueeze(dim=0)
-                    this_speech = self.token2wav(token=this_tok, prompt_token=flow_prompt_speech_token, prompt_feat=prompt_speech_feat,
-                                                 embedding=flow_embedding, uuid_=this_uuid, token_offset=token_offset, finalize=False)
-                    token_offset += self.token_hop_len
-                    yield {"tts_speech": this_speech.cpu()}
-                if self.llm_end_dict[this_uuid] is True and len(self.tts_speech_token_dict[this_uuid]) - token_offset < need:
-                    break
+
+        def check_llm():
+            err = self._llm_errors.pop(this_uuid, None)
+            if err is not None:
+                raise err
+
+        try:
+            if stream is True:
+                self.flow.length_bucket = self.stream_length_bucket
+                token_offset = 0
+                need = self.token_hop_len + self.flow.pre_lookahead_len
+                while True:
+                    time.sleep(0.02)
+                    if len(self.tts_speech_token_dict[this_uuid]) - token_offset >= need:
+                        this_tok = torch.tensor(self.tts_speech_token_dict[this_uuid][:token_offset + need]).unsqueeze(dim=0)
+                        this_speech = self.token2wav(token=this_tok, prompt_token=flow_prompt_speech_token, prompt_feat=prompt_speech_feat,
+                                                     embedding=flow_embedding, uuid_=this_uuid, token_offset=token_offset, finalize=False)
+                        token_offset += self.token_hop_len
+                        yield {"tts_speech": this_speech.cpu()}
+                    if self.llm_end_dict[this_uuid] is True and len(self.tts_speech_token_dict[this_uuid]) - token_offset < need:
+                        break
+                p.join()
+                check_llm()
+                this_tok = torch.tensor(self.tts_speech_token_dict[this_uuid]).unsqueeze(dim=0)
+                this_speech = self.token2wav(token=this_tok, prompt_token=flow_prompt_speech_token, prompt_feat=prompt_speech_feat,
+                                             embedding=flow_embedding, uuid_=this_uuid, token_offset=token_offset, finalize=True)
+                yield {"tts_speech": this_speech.cpu()}
+            else:
+                p.join()
+                check_llm()
+                this_tok = torch.tensor(self.tts_speech_token_dict[this_uuid]).unsqueeze(dim=0)
+                this_speech = self.token2wav(token=this_tok, prompt_token=flow_prompt_speech_token, prompt_feat=prompt_speech_feat,
+                                             embedding=flow_embedding, uuid_=this_uuid, token_offset=0, finalize=True, speed=speed)
+                yield {"tts_speech": this_speech.cpu()}
+        finally:
             p.join()
-            this_tok = torch.tensor(self.tts_speech_token_dict[this_uuid]).unsqueeze(dim=0)
-            this_speech = self.token2wav(token=this_tok, prompt_token=flow_prompt_speech_token, prompt_feat=prompt_speech_feat,
-                                         embedding=flow_embedding, uuid_=this_uuid, token_offset=token_offset, finalize=True)
-            yield {"tts_speech": this_speech.cpu()}
-        else:
-            p.join()
-            this_tok = torch.tensor(self.tts_speech_token_dict[this_uuid]).unsqueeze(dim=0)
-            this_speech = self.token2wav(token=this_tok, prompt_token=flow_prompt_speech_token, prompt_feat=prompt_speech_feat,
-                                         embedding=flow_embedding, uuid_=this_uuid, token_offset=0, finalize=True, speed=speed)
-            yield {"tts_speech": this_speech.cpu()}
-        with self.lock:
-            self.tts_speech_token_dict.pop(this_uuid)
-            self.llm_end_dict.pop(this_uuid)
-            self.hift_cache_dict.pop(this_uuid)
+            with self.lock:
+                self.tts_speech_token_dict.pop(this_uuid, None)
+                self.llm_end_dict.pop(this_uuid, None)
+                self.hift_cache_dict.pop(this_uuid, None)
+                self._llm_errors.pop(this_uuid, None)
 
     # ------------------------------------------------------------------ utterance-batched path (beyond the reference)
     @torch.no_grad()
@@ -299,7 +335,10 @@ class CosyVoice2Model:
         """Generator over a list of utterance batches (each a dict of tts_batch's arguments), software-pipelined the way
         the reference overlaps its LLM thread with flow/HiFT (cli/model.py:62,119,189): the LLM decode of later batches
         (latency-bound) runs while flow + HiFT of batch i (throughput-bound GEMMs) execute.  A batch may carry ``on_start``
-        (callable, e.g. the RCCL conditioning broadcast; called from the calling thread, in batch order).
+        (callable, e.g. the RCCL conditioning broadcast; called from the calling thread, in batch order) and ``on_done`` (callable,
+        called from the calling thread once the batch's result has been collected, i.e. when no job reads its inputs any more:
+        where a pipelined caller recycles the batch's conditioning buffer, cosyvoice_amd.dist.ConditioningRing).  ``batches`` may be
+        a generator: a batch is taken from it (and may acquire its buffers) only when the pipeline admits it.
 
         ``llm_cu_slots`` (default ``self.llm_cu_slots``) > 0 partitions the GPU: the decode loops run on that many CUs
         of every XCD and flow + HiFT on the others, each from its own host thread, every captured graph replayed launch by
@@ -482,16 +521,22 @@ class CosyVoice2Model:
                     lf = llm_pool.submit(llm_job, bs, ready, first)
                     for i, b in enumerate(bs):
                         last = nxt is None and i == len(bs) - 1
-                        inflight.append(flow_pool.submit(flow_job, b, lf, i, ready, flow_full if last else flow_part))
+                        inflight.append((b, flow_pool.submit(flow_job, b, lf, i, ready, flow_full if last else flow_part)))
                     first = False
-                yield collect(inflight.popleft())
+                b_done, fut = inflight.popleft()
+                try:
+                    wav = collect(fut)
+                finally:
+                    if b_done.get("on_done") is not None:
+                        b_done["on_done"]()   # every job of this batch (decode, flow, vocoder) has ended: its conditioning slot is free
+                yield wav
         if est is not None:
             est.cu_budget = 0
 
     @torch.no_grad()
     def _tts_batches_shared(self, batches, to_host):
         llm_stream = self.llm_context.stream if hasattr(self.llm_context, "stream") else torch.cuda.Stream()
-        pending = None
+        pending, pending_b = None, None
         for b in list(batches) + [None]:
             toks = None
             if b is not None:
@@ -503,13 +548,18 @@ class CosyVoice2Model:
                     toks = self.llm.generate_batch(b["texts"], b["prompt_texts"], b["llm_prompt_speech_tokens"], forced=b.get("forced"))
             if pending is not None:
                 if isinstance(pending, list):
-                    yield [w.cpu() for w in pending] if to_host else pending
+                    out = [w.cpu() for w in pending] if to_host else pending
                 else:
-                    yield pending.cpu() if to_host else pending.clone()
+                    out = pending.cpu() if to_host else pending.clone()
+                if not to_host:
+                    torch.cuda.current_stream().synchronize()   # on_done promises that nothing reads the batch's inputs any more
+                if pending_b.get("on_done") is not None:
+                    pending_b["on_done"]()
+                yield out
                 pending = None
             if toks is not None:
                 torch.cuda.current_stream().wait_event(ready)  # conditioning of this batch is in place
-                pending = self._flow_hift(b, toks)
+                pending, pending_b = self._flow_hift(b, toks), b
 
 
 class CosyVoiceModel(CosyVoice2Model):
@@ -580,7 +630,7 @@ class CosyVoiceModel(CosyVoice2Model):
 
     def _close(self, uuid_):
         with self.lock:
-            for d in (self.tts_speech_token_dict, self.llm_end_dict, self.mel_overlap_dict, self.hift_cache_dict, self.flow_cache_dict):
+            for d in (self.tts_speech_token_dict, self.llm_end_dict, self.mel_overlap_dict, self.hift_cache_dict, self.flow_cache_dict, self._llm_errors):
                 d.pop(uuid_, None)
 
     def _emit(self, uuid_, producer, flow_prompt_speech_token, prompt_speech_feat, flow_embedding, stream, speed, poll):
@@ -602,11 +652,18 @@ class CosyVoiceModel(CosyVoice2Model):
                     break
             if producer is not None:
                 producer.join()
+                self._raise_llm_error(uuid_)
             yield {"tts_speech": self.token2wav(token=toks(), finalize=True, **kw).cpu()}
         else:
             if producer is not None:
                 producer.join()
+                self._raise_llm_error(uuid_)
             yield {"tts_speech": self.token2wav(token=toks(), finalize=True, speed=speed, **kw).cpu()}
+
+    def _raise_llm_error(self, uuid_):
+        err = self._llm_errors.pop(uuid_, None)
+        if err is not None:
+            raise err
 
     def tts(self, text, flow_embedding, llm_embedding=torch.zeros(0, 512), prompt_text=torch.zeros(1, 0, dtype=torch.int32),
             llm_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32), flow_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32),

@@ -56,6 +56,20 @@ def bound_cache(cache: dict, key, *dependents, cap=None):
     return True
 
 
+def drop_graphs(*caches):
+    """Destroy every captured graph held in the given per-shape caches (values that are ops.Graph objects) and empty them, after
+    draining the device.  Called when the tensors a graph / descriptor has raw pointers into are about to be replaced
+    (load_state_dict on a model that has already run)."""
+    if not any(caches):
+        return
+    torch.cuda.synchronize()
+    for c in caches:
+        for g in c.values():
+            if hasattr(g, "destroy"):
+                g.destroy()
+        c.clear()
+
+
 class Recorder:
     """Collects the parameter blocks of cv_gemm / cv_layernorm / cv_attention calls instead of launching them, so a fixed
     launch sequence (the v1 LM's cached decode step) is built once and re-issued with a few patched fields per step: the

@@ -63,3 +63,9 @@ def test_argument_validation_returns_status_codes_without_a_gpu():
     assert lib.cv_pack_skinny(null, null, 16, 30, 0, null) < 0           # K % 32
     assert lib.cv_decode_attention(null, 0, null, null, None, 1, null, 0, 1, 14, 2, 704, ctypes.c_float(0.125), L.CV_BF16,
                                    None, 0, None, null) < 0
+    # pre-split ([8 hi | 8 lo]) outputs need whole groups of 8 channels: C = 12 would put the last group's lo half past the row
+    ptrs = (ctypes.c_void_p * 1)(16)
+    assert lib.cv_snake_multi(one, 4, 12, 12, 1, ptrs, ptrs, 12, L.CV_F32X3, null) < 0
+    assert lib.cv_snake_multi(one, 4, 16, 16, 1, ptrs, ptrs, 12, L.CV_F32X3, null) < 0
+    assert lib.cv_tblock_head(None, null) < 0 and lib.cv_tblock_tail(None, null) < 0
+    assert lib.cv_hift_decode_enqueue(None, null) < 0

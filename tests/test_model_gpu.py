@@ -258,3 +258,79 @@ def test_free_running_requests_differ_and_manual_seed_reproduces():
     assert a1 == b1 and a2 == b2
     assert a1 != a2
     assert len(m.llm._graphs) == n_graphs
+
+
+def test_tts_llm_thread_failure_reaches_the_caller():
+    """An exception inside the request's LLM thread must end the consumer loop (llm_end_dict is set in a finally) and be re-raised by
+    tts() in the calling thread — streaming and not — with the per-request state cleaned up and the decode context back in the pool."""
+    m, lc, fc, hc = _model()
+
+    class Boom(RuntimeError):
+        pass
+
+    orig = m.llm.new_context
+
+    def failing_context():
+        ctx = orig()
+
+        def inference(**kw):
+            yield 3
+            raise Boom("decode failed")
+        ctx.inference = inference
+        return ctx
+    m.llm.new_context = failing_context
+    for stream in (False, True):
+        with pytest.raises(Boom):
+            list(m.tts(**_inputs(lc, fc), stream=stream))
+        assert not m.tts_speech_token_dict and not m.llm_end_dict and not m.hift_cache_dict and not m._llm_errors
+    assert len(m._req_pool) == 1          # the one context made so far was released both times
+    assert all(c is not m.llm for c, _ in m._req_pool)   # self.llm stays reserved for tts_batch / tts_batches
+
+
+def test_reload_invalidates_descriptors_and_graphs():
+    """load_state_dict on stages that have already run: the HiFT decode descriptor (raw pointers of every conv tensor), the captured
+    decode-step graphs and the captured Euler loops are rebuilt — results after a second load equal a freshly built model's."""
+    from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
+    from cosyvoice_amd.hift import HiFTGenerator
+    from cosyvoice_amd.llm import Qwen2LM
+    lc, fc, hc = LlmConfig.tiny(), FlowConfig.tiny(), HiftConfig.tiny()
+    g = torch.Generator().manual_seed(4)
+    mel = torch.clamp(torch.randn(1, 80, 20, generator=g) * 2 - 6, -11.5, 2.0).cuda()
+    s = (torch.randn(1, 1, 20 * hc.total_upsample, generator=g) * 0.05).cuda()
+    sd_a, sd_b = hift_state_dict(hc, seed=1986), hift_state_dict(hc, seed=7)
+    h = HiFTGenerator(hc, dtype=torch.float32).load_state_dict(sd_a)
+    w_a = h.decode(mel, s).clone()
+    h.load_state_dict(sd_b)
+    w_b = h.decode(mel, s).clone()
+    w_ref = HiFTGenerator(hc, dtype=torch.float32).load_state_dict(sd_b).decode(mel, s).clone()
+    assert torch.equal(w_b, w_ref) and not torch.equal(w_a, w_b)
+    # LLM: teacher-forced log-probs through the captured step graph
+    text = torch.randint(0, lc.vocab_size, (1, 5), generator=g, dtype=torch.int32)
+    ptext = torch.randint(0, lc.vocab_size, (1, 3), generator=g, dtype=torch.int32)
+    pspeech = torch.randint(0, lc.speech_token_size, (1, 8), generator=g, dtype=torch.int32)
+    forced = torch.randint(0, lc.speech_token_size, (6,), generator=g).tolist()
+    la, lb = llm_state_dict(lc, seed=1986), llm_state_dict(lc, seed=11)
+    lm = Qwen2LM(lc, dtype=torch.float16, max_batch=2, ctx_max=128, max_out=64).load_state_dict(la)
+    p_a = lm.forced_logits(text, ptext, pspeech, forced).clone()
+    lm.load_state_dict(lb)
+    p_b = lm.forced_logits(text, ptext, pspeech, forced).clone()
+    p_ref = Qwen2LM(lc, dtype=torch.float16, max_batch=2, ctx_max=128, max_out=64).load_state_dict(lb).forced_logits(text, ptext, pspeech, forced)
+    assert torch.equal(p_b, p_ref) and not torch.equal(p_a, p_b)
+    # flow: the captured Euler loop
+    tok = torch.randint(0, fc.vocab_size, (1, 12), generator=g, dtype=torch.int32)
+    ptok = torch.randint(0, fc.vocab_size, (1, 6), generator=g, dtype=torch.int32)
+    pfeat = torch.clamp(torch.randn(1, 12, 80, generator=g) * 2 - 6, -11.5, 2.0)
+    emb = torch.randn(1, fc.spk_embed_dim, generator=g)
+    fa, fb = flow_state_dict(fc, seed=1986), flow_state_dict(fc, seed=13)
+    fl = CausalMaskedDiffWithXvec(fc, dtype=torch.float16).load_state_dict(fa)
+    fl.decoder.use_graph = True
+    for _ in range(2):
+        m_a = fl.inference_batch(tok, ptok, pfeat, emb).clone()
+    fl.load_state_dict(fb)
+    for _ in range(2):
+        m_b = fl.inference_batch(tok, ptok, pfeat, emb).clone()
+    fr = CausalMaskedDiffWithXvec(fc, dtype=torch.float16).load_state_dict(fb)
+    fr.decoder.use_graph = True
+    for _ in range(2):
+        m_ref = fr.inference_batch(tok, ptok, pfeat, emb).clone()
+    assert torch.equal(m_b, m_ref) and not torch.equal(m_a, m_b)
