@@ -169,7 +169,7 @@ class FlowTBlock(C.Structure):
 
 
 class FlowBlock(C.Structure):
-    _fields_ = [("res", FlowResnet), ("tb", C.POINTER(FlowTBlock)), ("n_tb", _i32), ("reserved", _i32)]
+    _fields_ = [("res", FlowResnet), ("tb", C.POINTER(FlowTBlock)), ("n_tb", _i32), ("fuse_tail_head", _i32)]
 
 
 class FlowSolverDesc(C.Structure):
@@ -254,7 +254,7 @@ EXPORTS = ["cv_version", "cv_arch", "cv_gemm", "cv_layernorm", "cv_attention",
            "cv_decode_attention", "cv_kv_retile", "cv_sample_ras", "cv_sizeof_skinny_params", "cv_sizeof_sample_params", "cv_anti_alias_act", "cv_anti_alias_act_cl",
            "cv_stft_magnitude", "cv_log_clamp_channels_first", "cv_groupnorm_cl", "cv_groupnorm_workspace_floats",
            "cv_interp_linear_cl", "cv_sizeof_groupnorm_params", "cv_relpos_append", "cv_sizeof_tblock_params", "cv_tblock_head",
-           "cv_tblock_tail", "cv_sizeof_llm_step_desc", "cv_sizeof_llm_layer", "cv_llm_step_enqueue", "cv_llm_step_graph_create",
+           "cv_tblock_tail", "cv_tblock_tail_head", "cv_sizeof_llm_step_desc", "cv_sizeof_llm_layer", "cv_llm_step_enqueue", "cv_llm_step_graph_create",
            "cv_llm_step_graph_launch", "cv_llm_step_graph_destroy", "cv_sizeof_resblock_params", "cv_resblock_conv1", "cv_resblock_conv2",
            "cv_sizeof_flow_solver_desc", "cv_sizeof_flow_block", "cv_sizeof_flow_tblock", "cv_flow_euler_enqueue",
            "cv_flow_euler_graph_create", "cv_flow_euler_graph_launch", "cv_flow_euler_graph_destroy",

@@ -161,38 +161,29 @@ __device__ __forceinline__ void ln_rows_to_lds(const float* xs, int ldx, int t0,
 // Fragment group G = 4 step + k-quarter lives in ring slot G % 4 = k-quarter and is refilled with group G + 4 once computed.
 // MT = MFMA row tiles per workgroup (rows per tile 16 MT = 64 or 48): 48-row tiles exist for grids that would otherwise run as
 // two rounds with the second nearly empty (256 tiles of 64 rows on the 192 CUs the pipeline leaves the flow stage).
-template <int DT, int MT, int ABL = 0>   // ABL: timing-only ablations (1: no output stores, 2: no ring refills)
-__global__ __launch_bounds__(NTHR, 2) void tblock_head_kernel(const cv_tblock_params p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lq = lane & 15, lg = lane >> 4;
-  const int r = blockIdx.y, t0 = blockIdx.x * (16 * MT);
-  const float* xs = p.x + (int64_t)r * p.T * p.ldx;
-  constexpr int NKS = TB_C / 32;                       // 8 k-steps
-  constexpr int NSTEP = 3 * TB_INNER / 16 / (4 * NW);  // 96 tiles / (8 waves x 4 tiles) = 3
+// fragment group G of the head's weight stream (clamped to the last step: harmless re-reads at the end): tiles (step * NW + w) * 4 + j,
+// k-steps 2 kq + u, into one ring slot
+__device__ __forceinline__ void head_ld(uint4 (&sl)[8], const __amdgpu_buffer_rsrc_t w_rs, int lane16, int wid, int G) {
+  constexpr int NKS = TB_C / 32, NSTEP = 3 * TB_INNER / 16 / (4 * NW);
+  const int st = min(G >> 2, NSTEP - 1), kq = G & 3;
+  const int tile0 = (st * NW + wid) * 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) sl[j * 2 + u] = frag_load(w_rs, lane16, (tile0 + j) * NKS + kq * 2 + u);
+  __builtin_amdgcn_sched_barrier(0);   // ring refills stay where they are written: NS - 1 fragment groups ahead of their use
+}
 
-  const __amdgpu_buffer_rsrc_t w_rs = frag_rsrc(p.wqkv_p, 96 * NKS);
-  const int lane16 = lane * 16;
-  uint4 s[NS][8];
-  // fragment group G (clamped to the last step: harmless re-reads at the end): tiles (step * NW + w) * 4 + j, k-steps 2 kq + u
+// The head's GEMM + stores over the 16 MT-row operand image at `img` (LayerNorm output, 512-byte rows).  On entry ring slots 0..3 hold
+// fragment groups 0..3 (head_ld) and the image is complete (barrier passed).
+template <int DT, int MT, int ABL>
+__device__ __forceinline__ void head_body(const cv_tblock_params& p, const char* img, uint4 (&s)[NS][8], const __amdgpu_buffer_rsrc_t w_rs,
+                                          int lane16, int wid, int lq, int lg, int r, int t0) {
+  constexpr int NSTEP = 3 * TB_INNER / 16 / (4 * NW);  // 96 tiles / (8 waves x 4 tiles) = 3
   auto ld = [&](uint4 (&sl)[8], int G) {
     if ((ABL & 2) && G >= NS) return;
-    const int st = min(G >> 2, NSTEP - 1), kq = G & 3;
-    const int tile0 = (st * NW + wid) * 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) sl[j * 2 + u] = frag_load(w_rs, lane16, (tile0 + j) * NKS + kq * 2 + u);
-    __builtin_amdgcn_sched_barrier(0);   // ring refills stay where they are written: NS - 1 fragment groups ahead of their use
+    head_ld(sl, w_rs, lane16, wid, G);
   };
-  ld(s[0], 0);
-  ld(s[1], 1);
-  ln_rows_to_lds<DT, MT>(xs, p.ldx, t0, p.T, p.g1, p.b1n, p.eps, smem, wid, lane);
-  ld(s[2], 2);
-  ld(s[3], 3);
-  __syncthreads();
-
   f32x4_t acc[MT][4];
   auto compute = [&](uint4 (&sl)[8], int kq, bool vpart) {
 #pragma unroll
@@ -200,7 +191,7 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_head_kernel(const cv_tblock_pa
       const int ks = kq * 2 + u;
       uint4 a[MT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a[i] = *(const uint4*)(smem + (16 * i + lq) * 512 + (swz16(lq, ks * 4 + lg) << 4));
+      for (int i = 0; i < MT; ++i) a[i] = *(const uint4*)(img + (16 * i + lq) * 512 + (swz16(lq, ks * 4 + lg) << 4));
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -278,6 +269,29 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_head_kernel(const cv_tblock_pa
   }
 }
 
+template <int DT, int MT, int ABL = 0>   // ABL: timing-only ablations (1: no output stores, 2: no ring refills)
+__global__ __launch_bounds__(NTHR, 2) void tblock_head_kernel(const cv_tblock_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lq = lane & 15, lg = lane >> 4;
+  const int r = blockIdx.y, t0 = blockIdx.x * (16 * MT);
+  const float* xs = p.x + (int64_t)r * p.T * p.ldx;
+  const __amdgpu_buffer_rsrc_t w_rs = frag_rsrc(p.wqkv_p, 96 * (TB_C / 32));
+  const int lane16 = lane * 16;
+  uint4 s[NS][8];
+  head_ld(s[0], w_rs, lane16, wid, 0);
+  head_ld(s[1], w_rs, lane16, wid, 1);
+  ln_rows_to_lds<DT, MT>(xs, p.ldx, t0, p.T, p.g1, p.b1n, p.eps, smem, wid, lane);
+  head_ld(s[2], w_rs, lane16, wid, 2);
+  head_ld(s[3], w_rs, lane16, wid, 3);
+  __syncthreads();
+  head_body<DT, MT, ABL>(p, smem, s, w_rs, lane16, wid, lq, lg, r, t0);
+}
+
+template <int MT>
+__device__ __forceinline__ void ln_acc(f32x4_t (&acc)[MT][2], float* red, const float* gam, const float* bet, float eps, int wid, int lq, int lg);
+
 // ============================================================================================== tail: to_out + LN + FFN
 // LDS: [0, 64 K) attention-output image (64 rows x 1024 B) during the out-projection, afterwards the xn image (64 x 512 B) at 0
 // and the first GELU chunk tile (64 x 512 B) at 32 K; [64 K, 96 K) second GELU chunk tile; [96 K, 100 K) cross-wave row
@@ -287,7 +301,12 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_head_kernel(const cv_tblock_pa
 // (32 MFMAs): 4 out-projection groups (k-steps 4 g ..+3 of 16), then per chunk c the groups q = 0, 1 (hidden layer, k-steps
 // 4 q ..+3 of 8) and q = 2, 3 (output layer, k-steps 8 c + 4 (q - 2) ..+3 of 32).  Group G lives in ring slot G % 4 and its slot
 // is refilled with group G + 4 once computed.
-template <int DT, bool OUTPROJ, int MT, int ABL = 0>   // ABL: timing-only ablations (1: GELU -> identity, 2: no ring refills)
+// NEXT = true: the kernel continues with the HEAD of the following transformer block on the same rows (cv_tblock_tail_head): the block
+// output stays in the accumulators, LayerNorm(norm1 of block i + 1) is taken from them (as norm3 above), the operand image replaces the xn
+// image, and the [Q | K | V^T] GEMM of head_body runs on it — the last FFN refills of the register ring already fetch the head's first
+// weight groups.  One launch and one 1 KB-per-row read of x less per block; the head fields of the parameter block (g1, b1n, wqkv_p, qk,
+// vt) then describe block i + 1.  LDS: two more staged vectors (g1 | b1n) behind the four of the tail.
+template <int DT, bool OUTPROJ, int MT, int ABL = 0, bool NEXT = false>   // ABL: timing-only ablations (1: GELU -> identity, 2: no ring refills)
 __global__ __launch_bounds__(NTHR, 2) void tblock_tail_kernel(const cv_tblock_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ximg = smem;
@@ -307,13 +326,18 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_tail_kernel(const cv_tblock_pa
   if (tid < 256) ((float4*)(smem + 102400))[tid] = ((const float4*)p.bf1)[tid];   // 1024 floats; visible after the first barrier
   vecs[tid] = tid < 256 ? (OUTPROJ ? p.bo[tid] : 0.f) : p.g3[tid - 256];
   vecs[512 + tid] = tid < 256 ? p.b3n[tid] : p.bf2[tid - 256];
+  if constexpr (NEXT) vecs[1024 + tid] = tid < 256 ? p.g1[tid] : p.b1n[tid - 256];
 
   const __amdgpu_buffer_rsrc_t w1_rs = frag_rsrc(p.w1_p, 64 * 8);    // [64 tiles][8 ks]
   const __amdgpu_buffer_rsrc_t w2_rs = frag_rsrc(p.w2_p, 16 * 32);   // [16 tiles][32 ks]
   const int lane16 = lane * 16;
   uint4 s[NS][8];
+  const __amdgpu_buffer_rsrc_t wh_rs = frag_rsrc(NEXT ? p.wqkv_p : p.w1_p, NEXT ? 96 * (TB_C / 32) : 64 * 8);   // NEXT: the following head's weights
   auto ld_ffn = [&](uint4 (&sl)[8], int f) {   // FFN group f = 4 c + q (clamped to the last chunk: harmless re-reads at the end)
     if ((ABL & 2) && f >= NS) return;
+    if constexpr (NEXT) {
+      if (f >= 4 * NC) { head_ld(sl, wh_rs, lane16, wid, f - 4 * NC); return; }   // ring slot f % 4 = head group f - 16 (its k-quarter)
+    }
     const int c = min(f >> 2, NC - 1), q = f & 3;
     if (q < 2) {   // hidden tiles 16 c + 2 w + j, k-steps 4 q + u
 #pragma unroll
@@ -521,17 +545,46 @@ __global__ __launch_bounds__(NTHR, 2) void tblock_tail_kernel(const cv_tblock_pa
   }
 
   // ---- store the block output (fp32 residual stream, in place) + optional 16-bit copy (skip connection / next conv operand)
-  uint16_t* oa = p.out_act ? (uint16_t*)p.out_act + (int64_t)r * p.T * p.ldoa : nullptr;
+  if constexpr (!NEXT) {
+    uint16_t* oa = p.out_act ? (uint16_t*)p.out_act + (int64_t)r * p.T * p.ldoa : nullptr;
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int t = t0 + 16 * i + lq;
-    if (t >= p.T) continue;
+    for (int i = 0; i < MT; ++i) {
+      const int t = t0 + 16 * i + lq;
+      if (t >= p.T) continue;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = ncol0 + 16 * j + 4 * lg;
-      *(float4*)(xs + (int64_t)t * p.ldx + n) = make_float4(acc2[i][j][0], acc2[i][j][1], acc2[i][j][2], acc2[i][j][3]);
-      if (oa) *(uint2*)(oa + (int64_t)t * p.ldoa + n) = pack4<DT>(acc2[i][j][0], acc2[i][j][1], acc2[i][j][2], acc2[i][j][3]);
+      for (int j = 0; j < 2; ++j) {
+        const int n = ncol0 + 16 * j + 4 * lg;
+        *(float4*)(xs + (int64_t)t * p.ldx + n) = make_float4(acc2[i][j][0], acc2[i][j][1], acc2[i][j][2], acc2[i][j][3]);
+        if (oa) *(uint2*)(oa + (int64_t)t * p.ldoa + n) = pack4<DT>(acc2[i][j][0], acc2[i][j][1], acc2[i][j][2], acc2[i][j][3]);
+      }
     }
+  } else {
+    // raw buffer stores (rows beyond T fall outside the descriptor and are dropped): no exec-masked branch between the head's weight
+    // prefetch, already in flight in the ring, and its first use
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)xs, 0, p.T * p.ldx * 4, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int t = t0 + 16 * i + lq;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{bitcast<uint32_t>(acc2[i][j][0]), bitcast<uint32_t>(acc2[i][j][1]),
+                                                       bitcast<uint32_t>(acc2[i][j][2]), bitcast<uint32_t>(acc2[i][j][3])},
+                                               x_rs, (t * p.ldx + ncol0 + 16 * j + 4 * lg) * 4, 0, 0);
+    }
+    // LayerNorm(norm1 of the next block) from the accumulators -> operand image at ximg (free since the last chunk's barrier: the
+    // hidden layer was its last reader; the output layer of that chunk reads himg1)
+    ln_acc<MT>(acc2, red, vecs + 1024, vecs + 1280, p.eps, wid, lq, lg);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = 16 * i + lq;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = ncol0 + 16 * j + 4 * lg;
+        *(uint2*)(ximg + m * 512 + (swz16(m, n >> 3) << 4) + ((lg & 1) << 3)) = pack4<DT>(acc2[i][j][0], acc2[i][j][1], acc2[i][j][2], acc2[i][j][3]);
+      }
+    }
+    __syncthreads();
+    head_body<DT, MT, 0>(p, ximg, s, wh_rs, lane16, wid, lq, lg, r, t0);
   }
 }
 
@@ -782,13 +835,13 @@ int env_int(const char* name, int dflt) { const char* e = getenv(name); return e
 template <typename K>
 void set_lds(K kern, size_t lds) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
 
-constexpr size_t TAIL_LDS = 98304 + 4096 + 4096 + 4096;
-template <int DT, bool OP, int MT, int ABL>
+constexpr size_t TAIL_LDS = 98304 + 4096 + 4096 + 4096 + 2048;
+template <int DT, bool OP, int MT, int ABL, bool NEXT = false>
 void launch_tail(const cv_tblock_params& p, hipStream_t st) {
   static PerDeviceOnce once;   // > 64 KiB of dynamic LDS needs the opt-in
-  once.run([] { set_lds(tblock_tail_kernel<DT, OP, MT, ABL>, TAIL_LDS); });
+  once.run([] { set_lds(tblock_tail_kernel<DT, OP, MT, ABL, NEXT>, TAIL_LDS); });
   dim3 grid((p.T + 16 * MT - 1) / (16 * MT), p.R);
-  hipLaunchKernelGGL((tblock_tail_kernel<DT, OP, MT, ABL>), grid, dim3(NTHR), TAIL_LDS, st, p);
+  hipLaunchKernelGGL((tblock_tail_kernel<DT, OP, MT, ABL, NEXT>), grid, dim3(NTHR), TAIL_LDS, st, p);
 }
 template <int DT, int MT, int ABL>
 void launch_head(const cv_tblock_params& p, hipStream_t st) {
@@ -830,6 +883,15 @@ void dispatch_head(const cv_tblock_params& p, hipStream_t st) {
     case 2: return launch_head<DT, 2, 0>(p, st);
     case 3: return launch_head<DT, 3, 0>(p, st);
     default: return launch_head<DT, 4, 0>(p, st);
+  }
+}
+template <int DT>
+void dispatch_tail_head(const cv_tblock_params& p, hipStream_t st) {
+  switch (pick_mt(p)) {
+    case 1: return launch_tail<DT, true, 1, 0, true>(p, st);
+    case 2: return launch_tail<DT, true, 2, 0, true>(p, st);
+    case 3: return launch_tail<DT, true, 3, 0, true>(p, st);
+    default: return launch_tail<DT, true, 4, 0, true>(p, st);
   }
 }
 template <int DT, bool OP>
@@ -879,6 +941,27 @@ extern "C" int cv_tblock_tail(const cv_tblock_params* pp, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (p.dtype == CV_BF16) { if (outproj) dispatch_tail<CV_BF16, true>(p, st); else dispatch_tail<CV_BF16, false>(p, st); }
   else { if (outproj) dispatch_tail<CV_F16, true>(p, st); else dispatch_tail<CV_F16, false>(p, st); }
+  CV_CHECK_LAUNCH();
+  return CV_OK;
+}
+
+// tail of block i + head of block i + 1 in one launch: tail fields = block i (to_out path required), head fields = block i + 1
+extern "C" int cv_tblock_tail_head(const cv_tblock_params* pp, void* stream) {
+  if (!pp) return CV_ERR_ARG;
+  const cv_tblock_params p = *pp;
+  if (int rc = check_common(p)) return rc;
+  if (!p.g3 || !p.b3n || !p.w1_p || !p.bf1 || !p.w2_p || !p.bf2 || !p.ao || !p.wo_p || !p.bo) return CV_ERR_ARG;
+  if (((uintptr_t)p.w1_p & 15) || ((uintptr_t)p.w2_p & 15) || ((uintptr_t)p.bf1 & 15) || (p.ldao & 7) || ((uintptr_t)p.ao & 15) || ((uintptr_t)p.wo_p & 15))
+    return CV_ERR_ARG;
+  if (p.out_act) return CV_ERR_ARG;   // the 16-bit copy belongs to the LAST block of a group, which has no following head
+  if (!p.g1 || !p.b1n || !p.wqkv_p || !p.qk || !p.vt) return CV_ERR_ARG;
+  if ((p.ldqk & 3) || (p.vt_ld & 3) || p.vt_ld < p.T || ((uintptr_t)p.qk & 7) || ((uintptr_t)p.vt & 7) || ((uintptr_t)p.wqkv_p & 15))
+    return CV_ERR_ARG;
+  if ((int64_t)p.T * p.ldqk * 2 >= (1ll << 31) || (int64_t)TB_INNER * p.vt_ld * 2 >= 0x7FFFFFF0ll || (int64_t)p.T * p.ldx * 4 >= (1ll << 31))
+    return CV_ERR_ARG;   // 32-bit buffer offsets
+  hipStream_t st = (hipStream_t)stream;
+  if (p.dtype == CV_BF16) dispatch_tail_head<CV_BF16>(p, st);
+  else dispatch_tail_head<CV_F16>(p, st);
   CV_CHECK_LAUNCH();
   return CV_OK;
 }

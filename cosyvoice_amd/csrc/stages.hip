@@ -152,12 +152,16 @@ int enqueue_estimator(const cv_flow_solver_desc& d, const float* tadd_row, hipSt
     }
     for (int j = 0; j < blk.n_tb; ++j) {
       const cv_flow_tblock& tb = blk.tb[j];
+      const bool last = j == blk.n_tb - 1;
+      const bool fuse = blk.fuse_tail_head != 0;
       cv_tblock_params p{};
       p.dtype = d.dtype; p.R = R; p.T = T; p.C = C; p.inner = inner; p.ff = d.ff;
       p.x = d.x32; p.ldx = C; p.eps = d.eps; p.cus = d.cus;
       p.g1 = tb.g1; p.b1n = tb.b1n; p.wqkv_p = tb.wqkv_p;
       p.qk = d.qk; p.ldqk = 2 * inner; p.vt = d.vt; p.vt_ld = d.Tp;
-      if (int rc = cv_tblock_head(&p, st)) return rc;
+      if (j == 0 || !fuse) {   // with fuse_tail_head the head of block j > 0 ran inside the previous block's tail launch
+        if (int rc = cv_tblock_head(&p, st)) return rc;
+      }
       cv_attn_params a{};
       a.dtype = d.dtype; a.B = R; a.H = d.heads; a.Hkv = d.heads; a.Tq = T; a.Tk = T;
       a.q = d.qk; a.q_bs = (int64_t)T * 2 * inner; a.ldq = 2 * inner;
@@ -168,12 +172,18 @@ int enqueue_estimator(const cv_flow_solver_desc& d, const float* tadd_row, hipSt
       if (int rc = cv_attention(&a, st)) return rc;
       p.ao = d.ao; p.ldao = inner; p.wo_p = tb.wo_p; p.bo = tb.bo; p.g3 = tb.g3; p.b3n = tb.b3n;
       p.w1_p = tb.w1_p; p.bf1 = tb.bf1; p.w2_p = tb.w2_p; p.bf2 = tb.bf2;
-      if (j == blk.n_tb - 1) {   // 16-bit copy of the block output: skip tensor / next block's conv input (decoder.py:277,301)
+      if (last) {   // 16-bit copy of the block output: skip tensor / next block's conv input (decoder.py:277,301)
         if (bi == 0) { p.out_act = (char*)d.cat + (size_t)C * esz; p.ldoa = 2 * C; }
         else if (bi == d.n_blocks - 2) { p.out_act = d.cat; p.ldoa = 2 * C; }
         else { p.out_act = d.d; p.ldoa = C; }
+        if (int rc = cv_tblock_tail(&p, st)) return rc;
+      } else if (fuse) {   // tail of block j + head of block j + 1 in one launch
+        const cv_flow_tblock& nx = blk.tb[j + 1];
+        p.g1 = nx.g1; p.b1n = nx.b1n; p.wqkv_p = nx.wqkv_p;
+        if (int rc = cv_tblock_tail_head(&p, st)) return rc;
+      } else {
+        if (int rc = cv_tblock_tail(&p, st)) return rc;
       }
-      if (int rc = cv_tblock_tail(&p, st)) return rc;
     }
     if (bi == 0) {   // downsample slot = CausalConv1d k3 on the skip tensor (decoder.py:278)
       if (int rc = conv_k3(d, (const char*)d.cat + (size_t)C * esz, 2 * C, d.down_w, d.down_b, d.d, nullptr, st)) return rc;

@@ -378,6 +378,58 @@ class ConditionalDecoder:
         ops.gemm(a_in, rs["wr"], T, C, cin, bias=rs["br"], res=c32b, res_bs=(T * C, 0), ldres=C, out_f32=ws["x32"],
                  o32_bs=(T * C, 0), ldo32=C, **kw)
 
+    def _tb_params(self, tb, ws, R):
+        """cv_tblock_params with the HEAD fields of ``tb`` filled in."""
+        inner = self.cfg.est_inner
+        p = ops.tblock_params(ws["x32"], R, ws["T"], 1e-5, self.dtype)
+        p.cus = int(getattr(self, "cu_budget", 0) or 0)   # CUs of the stream these launches go to (0 = all): tile-size choice only
+        p.g1, p.b1n, p.wqkv_p = tb["g1"].data_ptr(), tb["b1"].data_ptr(), tb["wqkv_p"].data_ptr()
+        p.qk, p.ldqk, p.vt, p.vt_ld = ws["qk"].data_ptr(), 2 * inner, ws["vt"].data_ptr(), ws["Tp"]
+        return p
+
+    def _tb_attention(self, ws, R, klen):
+        cfg = self.cfg
+        inner, H, T, Tp = cfg.est_inner, cfg.est_heads, ws["T"], ws["Tp"]
+        ops.attention(ws["qk"], ws["qk"][:, :, inner:], ws["vt"], ws["ao"], B=R, H=H, Hkv=H, Tq=T, Tk=T, scale=cfg.est_head_dim ** -0.5,
+                      q_bs=T * 2 * inner, ldq=2 * inner, k_bs=T * 2 * inner, ldk=2 * inner, vt_ld=Tp, o_bs=T * inner, ldo=inner, klen=klen)
+
+    def _tb_tail(self, tb, ws, R, out_act=None, ldoa=0, next_tb=None):
+        """Tail of ``tb``; with ``next_tb`` the same launch continues with that block's head (cv_tblock_tail_head)."""
+        p = self._tb_params(next_tb if next_tb is not None else tb, ws, R)
+        p.ao, p.ldao, p.wo_p, p.bo = ws["ao"].data_ptr(), self.cfg.est_inner, tb["wo_p"].data_ptr(), tb["bo"].data_ptr()
+        p.g3, p.b3n = tb["g3"].data_ptr(), tb["b3"].data_ptr()
+        p.w1_p, p.bf1, p.w2_p, p.bf2 = tb["wf1_p"].data_ptr(), tb["bf1"].data_ptr(), tb["wf2_p"].data_ptr(), tb["bf2"].data_ptr()
+        if next_tb is not None:
+            assert out_act is None
+            ops.tblock_tail_head(p)
+            return
+        if out_act is not None:
+            p.out_act, p.ldoa = out_act.data_ptr(), ldoa
+        ops.tblock_tail(p)
+
+    @property
+    def fuse_tail_head(self):
+        """Blocks j < n_tb - 1 of a group run their tail together with the next block's head (one launch, x not re-read)."""
+        return bool(self.fused) and os.environ.get("CV_FLOW_FUSE_TAIL_HEAD", "1") != "0"
+
+    def _tblock_group(self, tbs, ws, R, klen, out_act=None, ldoa=0):
+        """The n_tb transformer blocks behind one resnet block; the last one also leaves the 16-bit copy ``out_act``."""
+        if not (self.fused and all("wqkv_p" in tb for tb in tbs)):
+            for j, tb in enumerate(tbs):
+                last = j == len(tbs) - 1
+                self._tblock(tb, ws, R, klen, out_act=out_act if last else None, ldoa=ldoa if last else 0)
+            return
+        fuse = self.fuse_tail_head
+        for j, tb in enumerate(tbs):
+            last = j == len(tbs) - 1
+            if j == 0 or not fuse:
+                ops.tblock_head(self._tb_params(tb, ws, R))
+            self._tb_attention(ws, R, klen)
+            if last:
+                self._tb_tail(tb, ws, R, out_act=out_act, ldoa=ldoa)
+            else:
+                self._tb_tail(tb, ws, R, next_tb=tbs[j + 1] if fuse else None)
+
     def _tblock(self, tb, ws, R, klen, out_act=None, ldoa=0):
         cfg = self.cfg
         C, inner, ff, H = cfg.est_channels, cfg.est_inner, cfg.est_channels * cfg.est_ff_mult, cfg.est_heads
@@ -385,19 +437,9 @@ class ConditionalDecoder:
         rows = R * T
         if "wqkv_p" in tb and self.fused:
             # three launches: LN + [Q | K | V^T]  ->  flash attention  ->  to_out + residual + LN + FFN + residual
-            p = ops.tblock_params(ws["x32"], R, T, 1e-5, self.dtype)
-            p.cus = int(getattr(self, "cu_budget", 0) or 0)   # CUs of the stream these launches go to (0 = all): tile-size choice only
-            p.g1, p.b1n, p.wqkv_p = tb["g1"].data_ptr(), tb["b1"].data_ptr(), tb["wqkv_p"].data_ptr()
-            p.qk, p.ldqk, p.vt, p.vt_ld = ws["qk"].data_ptr(), 2 * inner, ws["vt"].data_ptr(), Tp
-            ops.tblock_head(p)
-            ops.attention(ws["qk"], ws["qk"][:, :, inner:], ws["vt"], ws["ao"], B=R, H=H, Hkv=H, Tq=T, Tk=T, scale=cfg.est_head_dim ** -0.5,
-                          q_bs=T * 2 * inner, ldq=2 * inner, k_bs=T * 2 * inner, ldk=2 * inner, vt_ld=Tp, o_bs=T * inner, ldo=inner, klen=klen)
-            p.ao, p.ldao, p.wo_p, p.bo = ws["ao"].data_ptr(), inner, tb["wo_p"].data_ptr(), tb["bo"].data_ptr()
-            p.g3, p.b3n = tb["g3"].data_ptr(), tb["b3"].data_ptr()
-            p.w1_p, p.bf1, p.w2_p, p.bf2 = tb["wf1_p"].data_ptr(), tb["bf1"].data_ptr(), tb["wf2_p"].data_ptr(), tb["bf2"].data_ptr()
-            if out_act is not None:
-                p.out_act, p.ldoa = out_act.data_ptr(), ldoa
-            ops.tblock_tail(p)
+            ops.tblock_head(self._tb_params(tb, ws, R))
+            self._tb_attention(ws, R, klen)
+            self._tb_tail(tb, ws, R, out_act=out_act, ldoa=ldoa)
             return
         x2 = ws["x32"].view(rows, C)
         ops.layernorm(x2, tb["g1"], tb["b1"], 1e-5, out_act=ws["xn"].view(rows, C))
@@ -425,18 +467,13 @@ class ConditionalDecoder:
         a_in, lda, cin = ws["xin"], cfg.est_in_channels, cfg.est_in_channels
         for bi, blk in enumerate(self.blocks):
             self._resnet(blk["res"], ws, R, a_in, lda, cin, tadd_row[bi * C:(bi + 1) * C])
-            ntb = len(blk["tb"])
-            for j, tb in enumerate(blk["tb"]):
-                last = j == ntb - 1
-                if not last:
-                    self._tblock(tb, ws, R, klen)
-                elif bi == 0:
-                    # skip connection: 16-bit copy into cat[:, :, C:2C] (hiddens.append, decoder.py:277)
-                    self._tblock(tb, ws, R, klen, out_act=cat[:, :, C:], ldoa=2 * C)
-                elif bi == nb - 2:
-                    self._tblock(tb, ws, R, klen, out_act=cat, ldoa=2 * C)  # last mid block -> cat[:, :, 0:C]
-                else:
-                    self._tblock(tb, ws, R, klen, out_act=ws["d"], ldoa=C)
+            if bi == 0:
+                # skip connection: 16-bit copy of the group's output into cat[:, :, C:2C] (hiddens.append, decoder.py:277)
+                self._tblock_group(blk["tb"], ws, R, klen, out_act=cat[:, :, C:], ldoa=2 * C)
+            elif bi == nb - 2:
+                self._tblock_group(blk["tb"], ws, R, klen, out_act=cat, ldoa=2 * C)  # last mid block -> cat[:, :, 0:C]
+            else:
+                self._tblock_group(blk["tb"], ws, R, klen, out_act=ws["d"], ldoa=C)
             if bi == 0:
                 # downsample slot = CausalConv1d k3 on the skip tensor (decoder.py:278)
                 ops.gemm(cat[:, :, C:], self.down_w, T, C, 3 * C, batch=R, a_bs=(T * 2 * C, 0), lda=2 * C, a_rows=T, cin=C,
@@ -531,7 +568,7 @@ class CausalConditionalCFM:
             run()
             return x
         key = (B, T, n_timesteps, x.data_ptr(), mu.data_ptr(), spks.data_ptr(), cond.data_ptr(),
-               0 if klen2 is None else klen2.data_ptr(), int(getattr(est, "cu_budget", 0) or 0), est.fused)
+               0 if klen2 is None else klen2.data_ptr(), int(getattr(est, "cu_budget", 0) or 0), est.fused, getattr(est, "fuse_tail_head", False))
         key = key + (stage_abi,)
         g = self._graphs.get(key)
         if g is None:
@@ -574,6 +611,7 @@ class CausalConditionalCFM:
                              ("w1_p", "wf1_p"), ("bf1", "bf1"), ("w2_p", "wf2_p"), ("bf2", "bf2")):
                     setattr(tbs[j], f, tb[k].data_ptr())
             blocks[bi].tb, blocks[bi].n_tb = tbs, len(blk["tb"])
+            blocks[bi].fuse_tail_head = int(est.fuse_tail_head)
         d.blocks = blocks
         for f in ("down_w", "down_b", "up_w", "up_b", "fin_w", "fin_b", "fin_g", "fin_be", "proj_w", "proj_b"):
             setattr(d, f, getattr(est, f).data_ptr())

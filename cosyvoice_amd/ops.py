@@ -214,6 +214,11 @@ def tblock_tail(p):
     _issue("cv_tblock_tail", p)
 
 
+def tblock_tail_head(p):
+    """Tail of block i (tail fields of p) + head of block i + 1 (head fields of p) in one launch."""
+    _issue("cv_tblock_tail_head", p)
+
+
 # ----------------------------------------------------------------------------- layout / HiFT helpers
 def to_channels_last(x, out):
     """x (B,C,T) fp32 -> out (B,T,ld) any dtype, zero-filled pad columns."""

@@ -176,6 +176,10 @@ typedef struct cv_tblock_params {
 int cv_sizeof_tblock_params(void);
 int cv_tblock_head(const cv_tblock_params* p, void* stream);
 int cv_tblock_tail(const cv_tblock_params* p, void* stream);
+/* tail of transformer block i followed, in the same launch and on the same rows, by the head of block i + 1: the tail fields describe
+ * block i (ao / wo_p / bo required, out_act must be NULL), the head fields (g1, b1n, wqkv_p, qk, vt) block i + 1.  Same results as
+ * cv_tblock_tail then cv_tblock_head up to the summation order of the fp32 LayerNorm statistics; x is written once and not re-read. */
+int cv_tblock_tail_head(const cv_tblock_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * cv_resblock_conv1 / cv_resblock_conv2 — CausalResnetBlock1D of the CFM estimator (flow/decoder.py:36-56 CausalBlock1D /
@@ -446,7 +450,9 @@ typedef struct cv_flow_tblock {
   const void* wo_p; const float* bo; const float* g3; const float* b3n;
   const void* w1_p; const float* bf1; const void* w2_p; const float* bf2;
 } cv_flow_tblock;
-typedef struct cv_flow_block { cv_flow_resnet res; const cv_flow_tblock* tb; int32_t n_tb; int32_t reserved; } cv_flow_block;
+typedef struct cv_flow_block { cv_flow_resnet res; const cv_flow_tblock* tb; int32_t n_tb;
+  int32_t fuse_tail_head;   /* != 0: blocks j < n_tb - 1 run as cv_tblock_tail_head (tail of j + head of j + 1 in one launch) */
+} cv_flow_block;
 typedef struct cv_flow_solver_desc {
   int32_t dtype, B, T, Tp;                 /* Tp = V^T row pitch (T rounded up to 8) */
   int32_t C, inner, ff, heads, in_ch, out_ch;   /* 256, 512, 1024, 8, 320, 80 */

@@ -102,6 +102,57 @@ def test_tail_vs_torch(dt, R, T, outproj, mt, monkeypatch):
     assert oa[:, :, :C].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("R,T", [(2, 150), (1, 64), (2, 65), (3, 1)])
+@pytest.mark.parametrize("mt", ["4", "3", "2", "1"])
+def test_tail_head_fused_equals_tail_then_head(dt, R, T, mt, monkeypatch):
+    """cv_tblock_tail_head (tail of block i + head of block i + 1 in one launch) against cv_tblock_tail followed by cv_tblock_head:
+    the fp32 residual stream x must be bit-identical (same accumulators, stored once); [Q | K] and V^T may differ by the summation
+    order of the LayerNorm statistics (taken from the accumulators instead of re-read rows) — a 16-bit ulp here and there — and both
+    are checked against torch fp32."""
+    from cosyvoice_amd import ops
+    monkeypatch.setenv("CV_TBLOCK_MT", mt)
+    w, w2 = _weights(dt, seed=2), _weights(dt, seed=7)       # block i, block i + 1
+    pk, pk2 = _packed(w, dt), _packed(w2, dt)
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(R, T, C, generator=g) * 2 + 0.3).cuda()
+    ao = torch.randn(R, T, INNER, generator=g).cuda().to(dt)
+    Tp = (T + 7) // 8 * 8
+
+    def run(fused):
+        xk = x.clone()
+        qk = torch.zeros(R, T, 2 * INNER, device="cuda", dtype=dt)
+        vt = torch.zeros(R, INNER // 64, 64, Tp, device="cuda", dtype=dt)
+        p = ops.tblock_params(xk, R, T, 1e-5, dt)
+        p.ao, p.ldao, p.wo_p, p.bo = ao.data_ptr(), INNER, pk["wo_p"].data_ptr(), w["bo"].data_ptr()
+        p.g3, p.b3n = w["g3"].data_ptr(), w["b3"].data_ptr()
+        p.w1_p, p.bf1, p.w2_p, p.bf2 = pk["w1_p"].data_ptr(), w["bf1"].data_ptr(), pk["w2_p"].data_ptr(), w["bf2"].data_ptr()
+        p.g1, p.b1n, p.wqkv_p = w2["g1"].data_ptr(), w2["b1"].data_ptr(), pk2["wqkv_p"].data_ptr()
+        p.qk, p.ldqk, p.vt, p.vt_ld = qk.data_ptr(), 2 * INNER, vt.data_ptr(), Tp
+        if fused:
+            ops.tblock_tail_head(p)
+        else:
+            ops.tblock_tail(p)
+            ops.tblock_head(p)
+        torch.cuda.synchronize()
+        return xk, qk, vt
+    x_f, qk_f, vt_f = run(True)
+    x_s, qk_s, vt_s = run(False)
+    assert torch.equal(x_f, x_s)
+    ref_x = _tail_ref(x, ao, w, dt)
+    xn = F.layer_norm(x_s, (C,), w2["g1"], w2["b1"], 1e-5).to(dt).float()
+    ref_qk = torch.cat([xn @ w2["wq"].t(), xn @ w2["wk"].t()], -1)
+    ref_v = xn @ w2["wv"].t()
+    tol = 2e-2 if dt == torch.bfloat16 else 3e-3
+    got_v = vt_f[..., :T].float().reshape(R, INNER, T).transpose(1, 2)
+    e_x, e_qk, e_v = (x_f - ref_x).abs().max().item(), (qk_f.float() - ref_qk).abs().max().item(), (got_v - ref_v).abs().max().item()
+    d_qk, d_v = (qk_f.float() - qk_s.float()).abs().max().item(), (vt_f.float() - vt_s.float()).abs().max().item()
+    print(f"tail+head[{dt},{R}x{T},MT={mt}]: x Linf {e_x:.3e}, qk {e_qk:.3e}, vt {e_v:.3e} vs torch; fused vs separate qk {d_qk:.2e} vt {d_v:.2e}")
+    assert e_x < (3e-2 if dt == torch.bfloat16 else 4e-3) and e_qk < tol and e_v < tol
+    assert d_qk < tol and d_v < tol
+    assert vt_f[..., T:].abs().max().item() == 0 if Tp > T else True
+
+
 def test_gelu_erf_polynomial():
     """The tail's erfc polynomial against torch's exact GELU over the whole useful range (through a 1-row FFN with identity-like
     weights is overkill: the tail test above already covers it at 16-bit; this pins the fp32 behaviour through W2 = I)."""
@@ -152,6 +203,45 @@ def test_fused_estimator_equals_unfused(dt, tol, monkeypatch):
     d = (outs[0] - outs[1]).abs()
     print(f"fused vs unfused [{dt}]: Linf {d.max().item():.3e} L1 {d.mean().item():.3e} (values ~ {outs[1].abs().mean().item():.2f})")
     assert d.max().item() < tol * max(1.0, outs[1].abs().max().item())
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 6e-3), (torch.bfloat16, 5e-2)])
+def test_estimator_tail_head_fusion_on_off(dt, tol, monkeypatch):
+    """The estimator with cv_tblock_tail_head launches (default) against the three-launches-per-block composition, eager and through
+    the stage ABI's captured solver: same kernels otherwise, LayerNorm statistics summed in a different order."""
+    from cosyvoice_amd.config import FlowConfig
+    from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
+    from cosyvoice_amd.weights import flow_state_dict
+    cfg = FlowConfig.tiny()
+    flow = CausalMaskedDiffWithXvec(cfg, dtype=dt).load_state_dict(flow_state_dict(cfg))
+    est = flow.decoder.estimator
+    R, T = 4, 150
+    g = torch.Generator().manual_seed(0)
+    xin = torch.randn(R, T, cfg.est_in_channels, generator=g).cuda().to(dt)
+    tt = est.time_table([0.3])
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CV_FLOW_FUSE_TAIL_HEAD", flag)
+        assert est.fuse_tail_head == (flag == "1")
+        ws = est._workspace(R, T)
+        ws["xin"].copy_(xin)
+        outs.append(est.forward_cl(ws, R, tt[0]).clone())
+    torch.cuda.synchronize()
+    d = (outs[0] - outs[1]).abs()
+    print(f"estimator tail+head fusion on vs off [{dt}]: Linf {d.max().item():.3e} (values ~ {outs[1].abs().mean().item():.2f})")
+    assert torch.isfinite(outs[0]).all() and d.max().item() < tol * max(1.0, outs[1].abs().max().item())
+    # whole flow: eager composition == captured stage-ABI solver, with the fusion on
+    monkeypatch.setenv("CV_FLOW_FUSE_TAIL_HEAD", "1")
+    tok = torch.randint(0, cfg.vocab_size, (2, 14), generator=g, dtype=torch.int32)
+    ptok = torch.randint(0, cfg.vocab_size, (2, 6), generator=g, dtype=torch.int32)
+    pfeat = torch.clamp(torch.randn(2, 12, 80, generator=g) * 2 - 6, -11.5, 2.0)
+    emb = torch.randn(2, cfg.spk_embed_dim, generator=g)
+    flow.decoder.use_graph = False
+    m_eager = flow.inference_batch(tok, ptok, pfeat, emb).clone()
+    flow.decoder.use_graph = True
+    flow.inference_batch(tok, ptok, pfeat, emb)
+    m_graph = flow.inference_batch(tok, ptok, pfeat, emb).clone()
+    assert torch.equal(m_eager, m_graph)
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float16, 6e-3), (torch.bfloat16, 5e-2)])
