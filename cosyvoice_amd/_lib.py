@@ -74,7 +74,7 @@ class AttnParams(C.Structure):
         ("out", _vp), ("o_bs", _i64), ("ldo", _i32),
         ("scale", _f32),
         ("klen", _vp), ("chunk", _i32), ("causal", _i32), ("causal_off", _i32),
-        ("bias", _vp), ("bias_bs", _i64), ("bias_hs", _i64), ("bias_ld", _i32),
+        ("bias", _vp), ("bias_bs", _i64), ("bias_hs", _i64), ("bias_ld", _i32), ("q_off", _i32),
         ("q_hs", _i64), ("k_hs", _i64),
     ]
 

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 2) void attn_kernel(const 
   int limit = klen;
   const int q_max = min(p.Tq, q_wg + QW) - 1;
   if (p.causal) limit = min(limit, q_max + p.causal_off + 1);
-  if (p.chunk > 0) limit = min(limit, (q_max / p.chunk + 1) * p.chunk);
+  if (p.chunk > 0) limit = min(limit, ((q_max + p.q_off) / p.chunk + 1) * p.chunk);
   const int ntiles = (limit + 63) >> 6;
 
   // ---- Q fragments (B operand of S^T): lane = query (lq), d chunk = ks*4 + lg.  Loads are unconditional (clamped
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 2) void attn_kernel(const 
         const int i = q0 + qt * 16 + lq;
         int jlim = klen;
         if (p.causal) jlim = min(jlim, i + p.causal_off + 1);
-        if (p.chunk > 0) jlim = min(jlim, (i / p.chunk + 1) * p.chunk);
+        if (p.chunk > 0) jlim = min(jlim, ((i + p.q_off) / p.chunk + 1) * p.chunk);
         if (p.bias != nullptr) {
           const float* brow = p.bias + (int64_t)b * p.bias_bs + (int64_t)h * p.bias_hs + (int64_t)min(i, p.Tq - 1) * p.bias_ld;
           // the lane's 16 bias values (two runs of 8 consecutive keys; the rel-pos view has no 16-byte alignment) as ONE batch of loads:
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 2) void attn_kernel(const 
   if (p.bias == nullptr) {
     int jmin = klen;
     if (p.causal) jmin = min(jmin, q0 + p.causal_off + 1);
-    if (p.chunk > 0) jmin = min(jmin, (q0 / p.chunk + 1) * p.chunk);
+    if (p.chunk > 0) jmin = min(jmin, ((q0 + p.q_off) / p.chunk + 1) * p.chunk);
     nfull = min(max(jmin, 0) >> 6, ntiles);
   }
   int t = 0;
@@ -340,6 +340,301 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 2) void attn_kernel(const 
   }
 }
 
+// ============================================================================================== 32x32x16 form
+// The same algorithm on v_mfma_f32_32x32x16: a wave still owns 32 queries, but as ONE 32-wide column block — lanes l and l + 32 share
+// query l & 31 and hold 16 + 16 of the 32 keys of a block.  Why: the kernel is ISSUE-bound (per 64-key tile a wave issues ~185 VALU +
+// 32 MFMAs; a 16x16x32 MFMA blocks the SIMD's vector issue for 8 of its 16 cycles, a 32x32x16 for 8 of its 32 — MI355X_MICROARCH.md,
+// cycle constants), so the same flops as 16 instead of 32 MFMAs free 128 issue cycles per tile-wave; the softmax bookkeeping (running
+// max, alpha, rescale test) runs once per 32 queries instead of twice, and the row max needs one cross-lane step instead of two.
+//   S^T block b (keys 32 b ..+31 of the tile) = K_b . Q^T: A = K rows, B = Q rows (k = d, 4 steps of 16);
+//   D layout: column = query l & 31, register v <-> MFMA row (v & 3) + 8 (v >> 2) + 4 h (h = l >> 5).
+// K rows are read PERMUTED (MFMA row m = key m with bits 2 and 3 swapped) so that registers 8 s .. 8 s + 7 of a lane are the 8
+// CONSECUTIVE keys 16 s + 8 h ..+7: packed to 16 bits they are the B operand of O^T += V^T . P^T (k-step s of the block) and the V^T
+// fragment is one 16-byte LDS read in natural key order ("An accumulator tile as the next MFMA's operand", cdna_hip_programming.md §3).
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+template <int DT>
+__device__ __forceinline__ f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c) {
+  if constexpr (DT == CV_BF16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(bitcast<bf16x8_t>(a), bitcast<bf16x8_t>(b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(bitcast<f16x8_t>(a), bitcast<f16x8_t>(b), c, 0, 0, 0);
+}
+
+template <int DT, int NWV, int ABL = 0>   // ABL: timing-only ablations (CV_ATTN_ABL; wrong results): 1 no K/V tile traffic after tile 0, 2 no softmax arithmetic
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 2) void attn32_kernel(const cv_attn_params p) {
+  constexpr int NT = 64 * NWV, QW = 32 * NWV, NL = 512 / NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  // K image: 64 keys x 128 B, chunk slot XOR (row >> 1) & 7.  MFMA row lr of block b reads key row 32 b + kperm(lr).
+  const int krow = (lr & 0x13) | ((lr & 4) << 1) | ((lr & 8) >> 1);   // bits 2 <-> 3
+  const int b = blockIdx.z, h = blockIdx.x;
+  const int hk = h / (p.H / p.Hkv);
+  const int q_wg = blockIdx.y * QW;
+  const int q0 = q_wg + wid * 32;
+
+  const uint16_t* Q = (const uint16_t*)p.q + (int64_t)b * p.q_bs + h * p.q_hs;
+  const uint16_t* Kp = (const uint16_t*)p.k + (int64_t)b * p.k_bs + hk * p.k_hs;
+  const uint16_t* Vt = (const uint16_t*)p.vt + (int64_t)(b * p.Hkv + hk) * 64 * p.vt_ld;
+  const int klen = p.klen ? min(p.klen[b], p.Tk) : p.Tk;
+
+  int limit = klen;
+  const int q_max = min(p.Tq, q_wg + QW) - 1;
+  if (p.causal) limit = min(limit, q_max + p.causal_off + 1);
+  if (p.chunk > 0) limit = min(limit, ((q_max + p.q_off) / p.chunk + 1) * p.chunk);
+  const int ntiles = (limit + 63) >> 6;
+
+  // ---- Q fragments (B operand): lane = query lr, d chunk 2 ks + lh
+  uint4 qf[4];
+  {
+    const int row = q0 + lr;
+    const uint32_t msk = row < p.Tq ? 0xFFFFFFFFu : 0u;
+    const int rc = min(row, p.Tq - 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const uint4 v = *(const uint4*)(Q + (int64_t)rc * p.ldq + (2 * ks + lh) * 8);
+      qf[ks] = make_uint4(v.x & msk, v.y & msk, v.z & msk, v.w & msk);
+    }
+  }
+
+  u32x4_t rk[NL], rv[NL];
+  int tile_j0 = 0;
+  const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)Kp, 0, klen > 0 ? (int)min(((int64_t)(klen - 1) * p.ldk + 64) * 2, (int64_t)0x7FFFFFFF) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)Vt, 0, (int)min((int64_t)64 * p.vt_ld * 2, (int64_t)0x7FFFFFFF), 0x00020000);
+  int koff[NL], voff[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int c = i * NT + tid;
+    const int r = c >> 3, dc = c & 7;
+    koff[i] = (r * p.ldk + dc * 8) * 2;
+    voff[i] = (r * p.vt_ld + dc * 8) * 2;
+  }
+  auto load_tile = [&](int t) {
+    const int j0 = t << 6;
+    tile_j0 = j0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      rk[i] = __builtin_amdgcn_raw_buffer_load_b128(k_rs, koff[i], j0 * p.ldk * 2, 0);
+      rv[i] = __builtin_amdgcn_raw_buffer_load_b128(v_rs, voff[i], j0 * 2, 0);
+    }
+  };
+  auto store_tile = [&](int s) {
+    char* sk = smem + s * STAGE_BYTES;
+    char* sv = sk + KT_BYTES;
+    const bool tail = tile_j0 + 64 > klen;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int c = i * NT + tid;
+      const int r = c >> 3, dc = c & 7;
+      *(u32x4_t*)(sk + (r << 7) + ((dc ^ ((r >> 1) & 7)) << 4)) = rk[i];
+      u32x4_t u = rv[i];
+      if (tail) {
+        const int nvalid = klen - (tile_j0 + dc * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t m_lo = (2 * e < nvalid) ? 0x0000FFFFu : 0u;
+          const uint32_t m_hi = (2 * e + 1 < nvalid) ? 0xFFFF0000u : 0u;
+          u[e] &= (m_lo | m_hi);
+        }
+      }
+      *(u32x4_t*)(sv + r * VT_PITCH + ((dc ^ ((r >> 1) & 7)) << 4)) = u;
+    }
+  };
+  // fragment addresses: K block b, d step ks: row 32 b + krow, chunk 2 ks + lh; V^T block db, key chunk c: row 32 db + lr, chunk c
+  int kaddr[2];
+#pragma unroll
+  for (int bb = 0; bb < 2; ++bb) kaddr[bb] = ((32 * bb + krow) << 7);
+  const int kswz = ((32 + krow) >> 1) & 7;   // (row >> 1) & 7 is the same for both blocks (32 >> 1 = 16 = 0 mod 8)
+  int vaddr[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db) vaddr[db] = (32 * db + lr) * VT_PITCH;
+  const int vswz = (lr >> 1) & 7;
+
+  f32x16_t oacc[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) oacc[db][v] = 0.f;
+  float mrun = NEG_BIG, lrun = 0.f;
+  const float sc = p.scale * 1.4426950408889634f;
+
+  if (ntiles > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  auto tile = [&](auto masked_tag, const int t) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    const int s = (ABL & 1) ? 0 : (t & 1);
+    if (!(ABL & 1) && t + 1 < ntiles) load_tile(t + 1);
+    const char* sk = smem + s * STAGE_BYTES;
+    const char* sv = sk + KT_BYTES;
+    const int j0 = t << 6;
+
+    // ---- S^T = K . Q^T, two 32-key blocks
+    f32x16_t sacc[2];
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+      f32x16_t a;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) a[v] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const uint4 kf = *(const uint4*)(sk + kaddr[bb] + (((2 * ks + lh) ^ kswz) << 4));
+        a = mfma32<DT>(kf, qf[ks], a);
+      }
+      sacc[bb] = a;
+    }
+
+    // key index of register v in block bb: j0 + 32 bb + 16 (v >> 3) + 8 lh + (v & 7)
+    float mnew;
+    bool dead = false;
+    if constexpr (MASKED) {
+      const int i = q0 + lr;
+      int jlim = klen;
+      if (p.causal) jlim = min(jlim, i + p.causal_off + 1);
+      if (p.chunk > 0) jlim = min(jlim, ((i + p.q_off) / p.chunk + 1) * p.chunk);
+      if (p.bias != nullptr) {
+        const float* brow = p.bias + (int64_t)b * p.bias_bs + (int64_t)h * p.bias_hs + (int64_t)min(i, p.Tq - 1) * p.bias_ld;
+        // one batch of 16 loads per 32-key block (both blocks at once would hold 32 more registers: spills at 168)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          float bv[16];
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int j = j0 + 32 * bb + 16 * (v >> 3) + 8 * lh + (v & 7);
+            bv[v] = brow[min(j, p.Tk - 1)];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int j = j0 + 32 * bb + 16 * (v >> 3) + 8 * lh + (v & 7);
+            const float x = fmaf(sacc[bb][v], sc, bv[v] * 1.4426950408889634f);
+            sacc[bb][v] = (j < jlim) ? x : NEG_BIG;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int j = j0 + 32 * bb + 16 * (v >> 3) + 8 * lh + (v & 7);
+            sacc[bb][v] = (j < jlim) ? sacc[bb][v] * sc : NEG_BIG;
+          }
+      }
+    }
+    // 32 in-lane scores -> two v_max3 chains, then the other half of the query's keys from lane ^ 32
+    float mx = fmaxf(fmaxf(sacc[0][0], sacc[0][1]), sacc[0][2]);
+    float my = fmaxf(fmaxf(sacc[1][0], sacc[1][1]), sacc[1][2]);
+#pragma unroll
+    for (int v = 3; v + 1 < 16; v += 2) {
+      mx = fmaxf(fmaxf(mx, sacc[0][v]), sacc[0][v + 1]);
+      my = fmaxf(fmaxf(my, sacc[1][v]), sacc[1][v + 1]);
+    }
+    mx = fmaxf(fmaxf(mx, sacc[0][15]), fmaxf(my, sacc[1][15]));
+    {
+      const uint32_t u = __float_as_uint(mx);
+      const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    const float scl = MASKED ? 1.0f : sc;
+    mnew = fmaxf(mrun, mx * scl);
+    if constexpr (MASKED) dead = mnew <= 0.5f * NEG_BIG;
+    const float nm = -mnew;
+    float ls0 = 0.f, ls1 = 0.f;
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+      for (int v = 0; v < 16; v += 2) {
+        if (ABL & 2) continue;
+        const float e0 = __builtin_amdgcn_exp2f(fmaf(sacc[bb][v], scl, nm));
+        const float e1 = __builtin_amdgcn_exp2f(fmaf(sacc[bb][v + 1], scl, nm));
+        sacc[bb][v] = e0;
+        sacc[bb][v + 1] = e1;
+        ls0 += e0;
+        ls1 += e1;
+      }
+    if constexpr (MASKED) {
+      if (dead) {
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) sacc[bb][v] = 0.f;
+        ls0 = ls1 = 0.f;
+      }
+    }
+    const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+    const bool same_max = __all(mnew == mrun);
+    mrun = mnew;
+    lrun = fmaf(lrun, alpha, ls0 + ls1);
+    if (!same_max) {
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) oacc[db][v] *= alpha;
+    }
+    // P^T fragments: block bb, k-step s2 = registers 8 s2 .. 8 s2 + 7 = keys 32 bb + 16 s2 + 8 lh ..+7
+    uint4 pf[2][2];
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        uint4 f;
+        f.x = pack2<DT>(sacc[bb][8 * s2 + 0], sacc[bb][8 * s2 + 1]);
+        f.y = pack2<DT>(sacc[bb][8 * s2 + 2], sacc[bb][8 * s2 + 3]);
+        f.z = pack2<DT>(sacc[bb][8 * s2 + 4], sacc[bb][8 * s2 + 5]);
+        f.w = pack2<DT>(sacc[bb][8 * s2 + 6], sacc[bb][8 * s2 + 7]);
+        pf[bb][s2] = f;
+      }
+
+    // ---- O^T += V^T . P^T: d block db (32 rows), key chunk c = 4 bb + 2 s2 + lh
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const uint4 vf = *(const uint4*)(sv + vaddr[db] + (((4 * bb + 2 * s2 + lh) ^ vswz) << 4));
+          oacc[db] = mfma32<DT>(vf, pf[bb][s2], oacc[db]);
+        }
+
+    if (!(ABL & 1) && t + 1 < ntiles) store_tile(s ^ 1);
+    __syncthreads();
+  };
+
+  int nfull = 0;
+  if (p.bias == nullptr) {
+    int jmin = klen;
+    if (p.causal) jmin = min(jmin, q0 + p.causal_off + 1);
+    if (p.chunk > 0) jmin = min(jmin, ((q0 + p.q_off) / p.chunk + 1) * p.chunk);
+    nfull = min(max(jmin, 0) >> 6, ntiles);
+  }
+  int t = 0;
+  for (; t < nfull; ++t) tile(std::false_type{}, t);
+  for (; t < ntiles; ++t) tile(std::true_type{}, t);
+
+  // ---- finalize: lane holds query lr, d = 32 db + 8 (v >> 2) + 4 lh + (v & 3)
+  uint16_t* O = (uint16_t*)p.out + (int64_t)b * p.o_bs + h * 64;
+  float l = lrun;
+  l += __shfl_xor(l, 32, 64);
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  const int i = q0 + lr;
+  if (i < p.Tq) {
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        uint2 u;
+        u.x = pack2<DT>(oacc[db][4 * g4 + 0] * inv, oacc[db][4 * g4 + 1] * inv);
+        u.y = pack2<DT>(oacc[db][4 * g4 + 2] * inv, oacc[db][4 * g4 + 3] * inv);
+        *(uint2*)(O + (int64_t)i * p.ldo + 32 * db + 8 * g4 + 4 * lh) = u;
+      }
+  }
+}
+
 }  // namespace
 
 extern "C" int cv_attention(const cv_attn_params* pp, void* stream) {
@@ -349,7 +644,7 @@ extern "C" int cv_attention(const cv_attn_params* pp, void* stream) {
   if (p.k_hs == 0) p.k_hs = 64;
   if ((p.q_hs & 7) || (p.k_hs & 7)) return CV_ERR_ARG;
   if (p.dtype != CV_BF16 && p.dtype != CV_F16) return CV_ERR_UNSUPPORTED;
-  if (p.B <= 0 || p.H <= 0 || p.Hkv <= 0 || (p.H % p.Hkv) || p.Tq <= 0 || p.Tk <= 0) return CV_ERR_ARG;
+  if (p.B <= 0 || p.H <= 0 || p.Hkv <= 0 || (p.H % p.Hkv) || p.Tq <= 0 || p.Tk <= 0 || p.q_off < 0) return CV_ERR_ARG;
   if (!p.q || !p.k || !p.vt || !p.out) return CV_ERR_ARG;
   if ((p.ldq & 7) || (p.ldk & 7) || (p.vt_ld & 7) || (p.ldo & 3) || (p.q_bs & 7) || (p.k_bs & 7) || (p.o_bs & 3)) return CV_ERR_ARG;
   if (p.vt_ld < p.Tk) return CV_ERR_ARG;
@@ -362,14 +657,31 @@ extern "C" int cv_attention(const cv_attn_params* pp, void* stream) {
   const int forced = fe ? atoi(fe) : 0;
   const int64_t wgs4 = (int64_t)p.H * ((p.Tq + 127) / 128) * p.B;
   const bool two = forced == 2 || (forced != 4 && wgs4 < 256);
+  const char* me = getenv("CV_ATTN_MFMA");   // 32 (default): the 32x32x16 form; 16: the 16x16x32 form (kept as its cross-check)
+  const bool m32 = !(me && atoi(me) == 16);
   if (two) {
     dim3 grid(p.H, (p.Tq + 63) / 64, p.B);
-    if (p.dtype == CV_BF16) hipLaunchKernelGGL((attn_kernel<CV_BF16, 2>), grid, dim3(128), lds, st, p);
-    else hipLaunchKernelGGL((attn_kernel<CV_F16, 2>), grid, dim3(128), lds, st, p);
+    if (m32) {
+      if (p.dtype == CV_BF16) hipLaunchKernelGGL((attn32_kernel<CV_BF16, 2>), grid, dim3(128), lds, st, p);
+      else hipLaunchKernelGGL((attn32_kernel<CV_F16, 2>), grid, dim3(128), lds, st, p);
+    } else {
+      if (p.dtype == CV_BF16) hipLaunchKernelGGL((attn_kernel<CV_BF16, 2>), grid, dim3(128), lds, st, p);
+      else hipLaunchKernelGGL((attn_kernel<CV_F16, 2>), grid, dim3(128), lds, st, p);
+    }
   } else {
     dim3 grid(p.H, (p.Tq + 127) / 128, p.B);
-    if (p.dtype == CV_BF16) hipLaunchKernelGGL((attn_kernel<CV_BF16, 4>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((attn_kernel<CV_F16, 4>), grid, dim3(256), lds, st, p);
+    if (m32) {
+      const char* ae = getenv("CV_ATTN_ABL");
+      const int abl = ae ? atoi(ae) : 0;
+      if (abl == 1 && p.dtype == CV_F16) hipLaunchKernelGGL((attn32_kernel<CV_F16, 4, 1>), grid, dim3(256), lds, st, p);
+      else if (abl == 2 && p.dtype == CV_F16) hipLaunchKernelGGL((attn32_kernel<CV_F16, 4, 2>), grid, dim3(256), lds, st, p);
+      else if (abl == 3 && p.dtype == CV_F16) hipLaunchKernelGGL((attn32_kernel<CV_F16, 4, 3>), grid, dim3(256), lds, st, p);
+      else if (p.dtype == CV_BF16) hipLaunchKernelGGL((attn32_kernel<CV_BF16, 4>), grid, dim3(256), lds, st, p);
+      else hipLaunchKernelGGL((attn32_kernel<CV_F16, 4>), grid, dim3(256), lds, st, p);
+    } else {
+      if (p.dtype == CV_BF16) hipLaunchKernelGGL((attn_kernel<CV_BF16, 4>), grid, dim3(256), lds, st, p);
+      else hipLaunchKernelGGL((attn_kernel<CV_F16, 4>), grid, dim3(256), lds, st, p);
+    }
   }
   CV_CHECK_LAUNCH();
   return CV_OK;

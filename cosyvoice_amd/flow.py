@@ -222,6 +222,121 @@ class UpsampleConformerEncoder:
         return ws
 
 
+
+    # ---- streaming: chunk-causal encoder cache (upsample_encoder.py:273-296 + utils/mask.py:127-200) -------------
+    # Under CosyVoice2Model's static chunk mask (50 tokens / 100 frames, cli/model.py:312-315) a position only attends to its own and
+    # earlier chunks, the look-ahead conv reaches 3 tokens to the right and every other op is pointwise or looks left.  So once
+    # n tokens are known, everything the encoder computes for positions < s = floor((n - 3) / chunk) * chunk — every layer's keys
+    # and values included — is final: a streaming request re-runs the encoder only on rows [s, n) of each chunk call, against
+    # per-layer K / V^T kept from the previous calls.  The reference re-encodes the whole sequence per chunk (cli/model.py:380-407);
+    # the result is the same up to the fp32 order of a score's scale-and-shift (a tile may be an "interior" tile in one call and a
+    # "masked" one in the other).
+    def new_stream_cache(self, cap_tokens: int = 1024):
+        return EncoderStreamCache(self, cap_tokens)
+
+    def _layer_cached(self, l, lc, loc, p_l, s, n, chunk, klen, last_act=None):
+        """One conformer layer on rows [s, n) (local tensors `loc`, M = n - s rows) against the layer cache `lc` = (q rows
+        [q+u | q+v | k] (cap, 3D), V^T (H, 64, cap_p)) that already holds rows [0, s) and receives rows [s, n)."""
+        cfg = self.cfg
+        D, H, U = cfg.enc_dim, cfg.enc_heads, cfg.enc_linear_units
+        M = n - s
+        qb, vtb = lc
+        capp = vtb.shape[2]
+        xs = loc["xs"][:M]
+        ops.layernorm(xs, l["g_mha"], l["b_mha"], 1e-12, out_act=loc["xn"][:M])
+        ops.linear(loc["xn"][:M], l["wqqk"], bias=l["bqqk"], out_act=qb[s:n])
+        # V^T of the new rows: through an 8-column-aligned scratch (the cache columns start at s = 50 k: not store-aligned)
+        Mp = _round_up(M, 8)
+        vt_new = loc["vt"][:D * Mp].view(D, Mp)
+        ops.gemm(l["wv"], loc["xn"], D, M, D, batch=1, lda=D, ldw=D, out_act=vt_new, ldoa=Mp)
+        vtb.view(D, capp)[:, s:n].copy_(vt_new[:, :M])
+        scale = 1.0 / math.sqrt(D // H)
+        ldb = _round_up(2 * n - 1, 4)
+        bd = loc["bd"].view(-1)[:H * M * ldb].view(H, M, ldb)
+        ops.gemm(qb[s:, D:], p_l, M, 2 * n - 1, 64, batch=H, batch_inner=H, a_bs=(64, 0), lda=3 * D, w_bs=(64, 0), ldw=D,
+                 out_scale=scale, out_f32=bd, o32_bs=(M * ldb, 0), ldo32=ldb)
+        ops.attention(qb[s:], qb[:, 2 * D:], vtb, loc["ao"], B=1, H=H, Hkv=H, Tq=M, Tk=n, scale=scale, q_bs=0, ldq=3 * D, k_bs=0,
+                      ldk=3 * D, vt_ld=capp, o_bs=0, ldo=D, klen=klen, chunk=chunk, q_off=s,
+                      bias=bd.view(-1)[n - 1 - s:], bias_bs=0, bias_hs=M * ldb, bias_ld=ldb - 1)
+        ops.linear(loc["ao"][:M], l["wout"], bias=l["bout"], res=xs, out_f32=xs)
+        ops.layernorm(xs, l["g_ff"], l["b_ff"], 1e-12, out_act=loc["xn"][:M])
+        ops.linear(loc["xn"][:M], l["w1"], bias=l["b1"], out_act=loc["ff"][:M], act=ops.ACT_SILU)
+        ops.linear(loc["ff"][:M], l["w2"], bias=l["b2"], res=xs, out_f32=xs, out_act=last_act)
+
+    def forward_tokens_cached(self, ec, tok_emb_act, N, Nv, klen=None):
+        """tok_emb_act (1, N, D): embeddings of all N (>= Nv real, rest padding) tokens.  Encodes rows [ec.n_done, N) and returns the
+        after_norm output of ALL 2N frames as ec.xa2[:2N] (16-bit); afterwards ec.n_done = the new stable prefix."""
+        cfg = self.cfg
+        D, U, H = cfg.enc_dim, cfg.enc_linear_units, cfg.enc_heads
+        chunk = int(self.static_chunk_size)
+        assert chunk > 0 and N <= ec.cap
+        dt, dev = self.dtype, self.device
+        s = min(ec.n_done, (max(Nv - cfg.pre_lookahead_len, 0) // chunk) * chunk)
+        M, c0 = N - s, max(s - 2, 0)          # rows to encode; first row the look-ahead convs need (2 rows of left context)
+        ML = N - c0
+        e = lambda *sh, dtype=torch.float32: torch.empty(*sh, device=dev, dtype=dtype)
+        # ---- N domain: embed rows [c0, N) -> look-ahead convs -> rows [s, N)
+        lin, xs0, xa0 = e(ML, D), e(ML, D), e(ML, D, dtype=dt)
+        ops.linear(tok_emb_act.view(N, D)[c0:], self.embed["w"], bias=self.embed["b"], out_f32=lin)
+        ops.layernorm(lin, self.embed["g"], self.embed["beta"], 1e-5, out_scale=math.sqrt(D), out_f32=xs0, out_act=xa0)
+        if Nv < N:   # padding rows read as the zero padding the look-ahead conv of the reference sees beyond the end
+            xs0[Nv - c0:].zero_()
+            xa0[Nv - c0:].zero_()
+        t1 = e(ML, D, dtype=dt)
+        ops.conv1d_cl(xa0.view(1, ML, D), self.pl1_w, cfg.pre_lookahead_len + 1, pad_left=0, bias=self.pl1_b, act=ops.ACT_LEAKY,
+                      act_slope=0.01, out_act=t1.view(1, ML, D))
+        loc = dict(xs=e(M, D), xn=e(M, D, dtype=dt), ao=e(M, D, dtype=dt), ff=e(M, U, dtype=dt), vt=e(D * _round_up(M, 8), dtype=dt),
+                   bd=e(H * M * _round_up(2 * N - 1, 4)))
+        if c0 == s - 2:   # conv2 output row s + q reads t1 rows s - 2 + q ..+2: a k3 conv without padding over the slice
+            ops.conv1d_cl(t1.view(1, ML, D), self.pl2_w, 3, pad_left=0, T_out=M, bias=self.pl2_b, res=xs0[2:].view(1, M, D),
+                          out_f32=loc["xs"].view(1, M, D))
+        else:             # s < 2 (s == 0): the sequence start, left zero padding as in the full pass
+            ops.conv1d_cl(t1.view(1, ML, D), self.pl2_w, 3, pad_left=2, bias=self.pl2_b, res=xs0.view(1, ML, D),
+                          out_f32=loc["xs"].view(1, M, D))
+        pa = self._pos_proj(self.layers, "a", N)
+        for i, l in enumerate(self.layers):
+            self._layer_cached(l, ec.a[i], loc, pa[i], s, N, chunk, klen,
+                               last_act=(ec.xa_last[2 + s:2 + N] if i == len(self.layers) - 1 else None))
+        # ---- upsample (two 3-tap phase convs over xa rows q - 2 .. q; ec.xa_last has two zero rows in front) -> frames [2s, 2N)
+        M2, s2, N2 = 2 * M, 2 * s, 2 * N
+        up = e(M2, D, dtype=dt)
+        for r in range(2):
+            ops.gemm(ec.xa_last[s:], self.up_w[r], M, D, 3 * D, batch=1, lda=D, a_rows=M + 2, cin=D, tap_base=0, tap_step=1,
+                     bias=self.up_b, out_act=up, ldoa=D, out_row_stride=2, out_row_off=r, out_rows=M2)
+        lin2 = e(M2, D)
+        loc2 = dict(xs=e(M2, D), xn=e(M2, D, dtype=dt), ao=e(M2, D, dtype=dt), ff=e(M2, U, dtype=dt), vt=e(D * _round_up(M2, 8), dtype=dt),
+                    bd=e(H * M2 * _round_up(2 * N2 - 1, 4)))
+        ops.linear(up, self.up_embed["w"], bias=self.up_embed["b"], out_f32=lin2)
+        ops.layernorm(lin2, self.up_embed["g"], self.up_embed["beta"], 1e-5, out_scale=math.sqrt(D), out_f32=loc2["xs"])
+        pb = self._pos_proj(self.up_layers, "b", N2)
+        klen2 = (klen * 2) if klen is not None else None
+        for i, l in enumerate(self.up_layers):
+            self._layer_cached(l, ec.b[i], loc2, pb[i], s2, N2, 2 * chunk, klen2)
+        ops.layernorm(loc2["xs"], self.after_g, self.after_b, 1e-5, out_act=ec.xa2[s2:N2])
+        ec.n_done = (max(Nv - cfg.pre_lookahead_len, 0) // chunk) * chunk
+        ec.rows_encoded += M
+        ec.calls += 1
+        return ec.xa2[:N2]
+
+
+class EncoderStreamCache:
+    """Per-request state of UpsampleConformerEncoder.forward_tokens_cached: for each of the 6 + 4 layers the [q+u | q+v | k] rows and V^T
+    of every position seen so far, the N-domain output rows the upsampling conv looks back on, and the after_norm output of every frame."""
+
+    def __init__(self, enc: "UpsampleConformerEncoder", cap_tokens: int):
+        cfg, dt, dev = enc.cfg, enc.dtype, enc.device
+        D, H = cfg.enc_dim, cfg.enc_heads
+        self.cap = int(cap_tokens)
+        z = lambda *sh: torch.zeros(*sh, device=dev, dtype=dt)
+        capp, capp2 = _round_up(self.cap, 8), _round_up(2 * self.cap, 8)
+        self.a = [(z(self.cap, 3 * D), z(H, 64, capp)) for _ in enc.layers]
+        self.b = [(z(2 * self.cap, 3 * D), z(H, 64, capp2)) for _ in enc.up_layers]
+        self.xa_last = z(self.cap + 2, D)          # logical row r at index r + 2 (two rows of left zero padding)
+        self.xa2 = z(2 * self.cap, D)              # after_norm output, all frames
+        self.n_done = 0                            # tokens whose encoding is final
+        self.rows_encoded, self.calls = 0, 0       # diagnostics: token rows run through the layers / calls
+
+
 # =============================================================================== estimator
 class ConditionalDecoder:
     """The CFM estimator (flow/decoder.py:88-334, channels=[256], causal).  ``__call__`` keeps the reference slot
@@ -654,6 +769,7 @@ class CausalMaskedDiffWithXvec:
         self.decoder = CausalConditionalCFM(self.cfg, ConditionalDecoder(self.cfg, dtype, self.device), self.device)
         self._loaded = False
         self._bufs: Dict[tuple, dict] = {}
+        self._stream_caches: Dict[object, "EncoderStreamCache"] = {}   # cache_key of a streaming request -> its encoder cache
 
     def to(self, *a, **k):
         return self
@@ -698,9 +814,11 @@ class CausalMaskedDiffWithXvec:
 
     @torch.no_grad()
     def inference_batch(self, tokens: torch.Tensor, prompt_tokens: torch.Tensor, prompt_feats: torch.Tensor,
-                        embeddings: torch.Tensor, n_timesteps: int = 10):
+                        embeddings: torch.Tensor, n_timesteps: int = 10, stream_cache=None):
         """B equal-shape utterances.  tokens (B,Ng) i32, prompt_tokens (B,Np), prompt_feats (B,Tp,80) with Tp = 2*Np,
-        embeddings (B,D) -> mel (B,80,2*Ng) fp32.  Per utterance identical to ``inference`` (flow.py:258-319)."""
+        embeddings (B,D) -> mel (B,80,2*Ng) fp32.  Per utterance identical to ``inference`` (flow.py:258-319).
+        ``stream_cache`` (EncoderStreamCache, B = 1): a streaming request's chunk call — the encoder only runs on the rows behind
+        the cached chunk-causal prefix (UpsampleConformerEncoder.forward_tokens_cached)."""
         assert self._loaded
         cfg, dev = self.cfg, self.device
         B, Ng = tokens.shape
@@ -732,8 +850,12 @@ class CausalMaskedDiffWithXvec:
             klen_est.fill_(2 * Nv)
         ews = self.encoder._workspace(B, N)
         ops.embedding(self.emb_table, bf["idx"].view(-1), ews["tok"].view(B * N, cfg.enc_dim))
-        self.encoder.forward_tokens(ews["tok"], B, N, klen=klen_enc, n_valid=Nv if padded else None)
-        ops.linear(ews["b"]["xa"].view(B * T, cfg.enc_dim), self.proj_w, bias=self.proj_b, out_f32=ews["mu"].view(B * T, cfg.output_size))
+        if stream_cache is not None and B == 1 and int(self.encoder.static_chunk_size) > 0 and N <= stream_cache.cap:
+            xa = self.encoder.forward_tokens_cached(stream_cache, ews["tok"], N, Nv, klen=klen_enc)
+        else:
+            self.encoder.forward_tokens(ews["tok"], B, N, klen=klen_enc, n_valid=Nv if padded else None)
+            xa = ews["b"]["xa"]
+        ops.linear(xa.view(B * T, cfg.enc_dim), self.proj_w, bias=self.proj_b, out_f32=ews["mu"].view(B * T, cfg.output_size))
         # conditions: prompt mel then zeros (flow.py:305-307)
         Tp = prompt_feats.shape[1]
         bf["cond"].zero_()
@@ -781,10 +903,18 @@ class CausalMaskedDiffWithXvec:
         ops.to_channels_first(bf["x"], bf["mel"])
         return [bf["mel"][b, :, 2 * nps[b]:2 * nvs[b]].clone() for b in range(B)]
 
+    supports_stream_cache = True
+
+    def drop_stream_cache(self, cache_key):
+        """End of a streaming request: release its encoder cache."""
+        self._stream_caches.pop(cache_key, None)
+
     @torch.no_grad()
     def inference(self, token, token_len, prompt_token, prompt_token_len, prompt_feat, prompt_feat_len, embedding,
-                  flow_cache=None, sample_rate=24000, n_timesteps=10, begin=False, finalize=True):
-        """Reference signature (flow.py:260-272) -> (mel (1,80,T_g) float32, None)."""
+                  flow_cache=None, sample_rate=24000, n_timesteps=10, begin=False, finalize=True, cache_key=None):
+        """Reference signature (flow.py:260-272) -> (mel (1,80,T_g) float32, None).  ``cache_key`` (extra keyword, absent from the
+        reference): identifies a streaming request across its chunk calls; its chunk-causal encoder state is then kept between the
+        calls (CV_STREAM_ENC_CACHE=0 turns that off: every call re-encodes everything, as the reference does)."""
         assert token.shape[0] == 1
         r = self.token_mel_ratio
         if int(prompt_feat_len[0]) % r != 0:  # flow.py:279-283 (mutates the length tensors in place, as the reference)
@@ -792,5 +922,14 @@ class CausalMaskedDiffWithXvec:
             prompt_feat = prompt_feat[:, :int(prompt_feat_len[0]), :]
             prompt_token_len[0] = prompt_feat_len[0] // r
             prompt_token = prompt_token[:, :int(prompt_token_len[0])]
-        mel = self.inference_batch(token, prompt_token, prompt_feat, embedding, n_timesteps)
+        ec = None
+        if cache_key is not None and os.environ.get("CV_STREAM_ENC_CACHE", "1") != "0" and int(self.encoder.static_chunk_size) > 0:
+            need = int(prompt_token.shape[1] + token.shape[1]) + 64
+            ec = self._stream_caches.get(cache_key)
+            if ec is None or ec.cap < need:     # first call of the request, or the request outgrew its cache: start over, larger
+                while len(self._stream_caches) >= 8:
+                    self._stream_caches.pop(next(iter(self._stream_caches)))
+                ec = self.encoder.new_stream_cache(max(1024, _round_up(2 * need, 256)))
+                self._stream_caches[cache_key] = ec
+        mel = self.inference_batch(token, prompt_token, prompt_feat, embedding, n_timesteps, stream_cache=ec)
         return mel.float().clone(), None

@@ -183,7 +183,10 @@ class CosyVoice2Model:
                                          prompt_token_len=torch.tensor([prompt_token.shape[1]], dtype=torch.int32),
                                          prompt_feat=prompt_feat.to(self.device),
                                          prompt_feat_len=torch.tensor([prompt_feat.shape[1]], dtype=torch.int32),
-                                         embedding=embedding.to(self.device), finalize=finalize)
+                                         embedding=embedding.to(self.device), finalize=finalize,
+                                         # a streaming request's chunk calls share its chunk-causal encoder state
+                                         **({"cache_key": uuid_} if (getattr(self.flow, "supports_stream_cache", False)
+                                                                     and (not finalize or token_offset > 0)) else {}))
         tts_mel = tts_mel[:, :, token_offset * self.flow.token_mel_ratio:]
         if self.hift_cache_dict[uuid_] is not None:
             hift_cache_mel, hift_cache_source = self.hift_cache_dict[uuid_]["mel"], self.hift_cache_dict[uuid_]["source"]
@@ -262,6 +265,8 @@ class CosyVoice2Model:
                 self.llm_end_dict.pop(this_uuid, None)
                 self.hift_cache_dict.pop(this_uuid, None)
                 self._llm_errors.pop(this_uuid, None)
+            if getattr(self.flow, "supports_stream_cache", False):
+                self.flow.drop_stream_cache(this_uuid)
 
     # ------------------------------------------------------------------ utterance-batched path (beyond the reference)
     @torch.no_grad()

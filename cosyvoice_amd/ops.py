@@ -180,7 +180,7 @@ def layernorm(x, gamma, beta, eps, *, rms=False, add=None, rows_per_group=0, act
 
 
 def attention(q, k, vt, out, *, H, Hkv, Tq, Tk, scale, q_bs, ldq, k_bs, ldk, vt_ld, o_bs, ldo, B, klen=None, chunk=0,
-              causal=False, causal_off=0, bias=None, bias_bs=0, bias_hs=0, bias_ld=0, q_hs=0, k_hs=0):
+              causal=False, causal_off=0, bias=None, bias_bs=0, bias_hs=0, bias_ld=0, q_hs=0, k_hs=0, q_off=0):
     _req_cuda(q, k, vt, out, klen, bias)
     p = L.AttnParams()
     p.dtype = L.TORCH_DT[q.dtype]
@@ -191,7 +191,7 @@ def attention(q, k, vt, out, *, H, Hkv, Tq, Tk, scale, q_bs, ldq, k_bs, ldk, vt_
     p.out, p.o_bs, p.ldo = out.data_ptr(), o_bs, ldo
     p.scale, p.klen, p.chunk, p.causal, p.causal_off = scale, L.ptr(klen), chunk, int(causal), causal_off
     p.bias, p.bias_bs, p.bias_hs, p.bias_ld = L.ptr(bias), bias_bs, bias_hs, bias_ld
-    p.q_hs, p.k_hs = q_hs, k_hs
+    p.q_hs, p.k_hs, p.q_off = q_hs, k_hs, q_off
     _issue("cv_attention", p)
 
 

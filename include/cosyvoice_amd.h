@@ -135,6 +135,8 @@ typedef struct cv_attn_params {
   int32_t chunk;            /* 0 = off */
   int32_t causal; int32_t causal_off;
   const float* bias; int64_t bias_bs, bias_hs; int32_t bias_ld; /* fp32 additive bias view or null */
+  int32_t q_off;            /* chunk mask: query row i sits at position q_off + i of the key sequence (incremental encoder: only the
+                               rows behind the cached prefix are queries); 0 = queries and keys start together */
   int64_t q_hs, k_hs;       /* element stride between heads of Q / K (0 -> 64: heads packed inside a row) */
 } cv_attn_params;
 int cv_attention(const cv_attn_params* p, void* stream);
