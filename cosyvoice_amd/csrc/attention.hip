@@ -635,6 +635,300 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 2) void attn32_kernel(cons
   }
 }
 
+// ============================================================================================== 64 queries per wave
+// attn64_kernel: the 32x32x16 form with TWO 32-query blocks per wave (workgroup = 4 waves = 256 queries, 2 workgroups per CU at 256
+// VGPRs) and the K / V^T tiles brought in by LDS-DMA (global_load_lds, 1 KiB per wave-instruction: no staging registers, none of the
+// 13-cycle ds_write_b128 of the register-staged path).  Every K / V^T fragment read from LDS now feeds two MFMAs, and a tile is staged
+// once per 256 queries instead of once per 128: the r03 ablations of the 128-query kernel put its tile traffic at 11 of 59 us and its
+// MFMA + LDS-read skeleton at 38 us (3 x the MFMA floor).  No bias operand (the encoder's rel-pos attention keeps the 32-query forms).
+// LDS-DMA writes lane l of a wave-instruction at base + 16 l, i.e. 8 rows x 8 chunk slots of the row-major image: the XOR swizzle
+// goes on the SOURCE (lane (row, slot) fetches chunk slot ^ swz(row)).
+template <int DT>
+__global__ __launch_bounds__(256, 2) void attn64_kernel(const cv_attn_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int krow = (lr & 0x13) | ((lr & 4) << 1) | ((lr & 8) >> 1);   // MFMA row -> key row: bits 2 <-> 3 (see attn32_kernel)
+  const int b = blockIdx.z, h = blockIdx.x;
+  const int hk = h / (p.H / p.Hkv);
+  const int q_wg = blockIdx.y * 256;
+  const int q0 = q_wg + wid * 64;
+
+  const uint16_t* Q = (const uint16_t*)p.q + (int64_t)b * p.q_bs + h * p.q_hs;
+  const uint16_t* Kp = (const uint16_t*)p.k + (int64_t)b * p.k_bs + hk * p.k_hs;
+  const uint16_t* Vt = (const uint16_t*)p.vt + (int64_t)(b * p.Hkv + hk) * 64 * p.vt_ld;
+  const int klen = p.klen ? min(p.klen[b], p.Tk) : p.Tk;
+
+  int limit = klen;
+  const int q_max = min(p.Tq, q_wg + 256) - 1;
+  if (p.causal) limit = min(limit, q_max + p.causal_off + 1);
+  if (p.chunk > 0) limit = min(limit, ((q_max + p.q_off) / p.chunk + 1) * p.chunk);
+  const int ntiles = (limit + 63) >> 6;
+
+  // ---- Q fragments (B operand): query block qb, d step ks: row q0 + 32 qb + lr, chunk 2 ks + lh
+  uint4 qf[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int row = q0 + 32 * qb + lr;
+    const uint32_t msk = row < p.Tq ? 0xFFFFFFFFu : 0u;
+    const int rc = min(row, p.Tq - 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const uint4 v = *(const uint4*)(Q + (int64_t)rc * p.ldq + (2 * ks + lh) * 8);
+      qf[qb][ks] = make_uint4(v.x & msk, v.y & msk, v.z & msk, v.w & msk);
+    }
+  }
+
+  // ---- LDS-DMA: wave w, instruction i (0, 1): the 1 KiB block 4 i + w of the K image and of the V^T image
+  int drow[2], dchunk[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    drow[i] = (4 * i + wid) * 8 + (lane >> 3);
+    dchunk[i] = (lane & 7) ^ ((drow[i] >> 1) & 7);
+  }
+  auto dma_tile = [&](int t, int stage) {
+    const int j0 = t << 6;
+    char* sk = smem + stage * STAGE_BYTES;
+    char* sv = sk + KT_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      // rows / columns beyond the tensors are clamped to valid memory: their scores are masked (select, not multiply) and the
+      // V^T columns beyond klen are zeroed in LDS before the tail tile is used
+      const uint16_t* ks_ = Kp + (int64_t)min(j0 + drow[i], p.Tk - 1) * p.ldk + dchunk[i] * 8;
+      const uint16_t* vs_ = Vt + (int64_t)drow[i] * p.vt_ld + min(j0 + dchunk[i] * 8, p.vt_ld - 8);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)ks_, (lds_ptr_t)(sk + (4 * i + wid) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)vs_, (lds_ptr_t)(sv + (4 * i + wid) * 1024), 16, 0, 0);
+    }
+  };
+  // the tail tile (keys beyond klen inside it): zero those V^T columns (0 * garbage must not become NaN)
+  auto fix_tail = [&](int t, int stage) {
+    const int j0 = t << 6;
+    char* sv = smem + stage * STAGE_BYTES + KT_BYTES;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int c = tid * 2 + e;
+      const int d = c >> 3, slot = c & 7;
+      const int kc = slot ^ ((d >> 1) & 7);
+      const int nvalid = klen - (j0 + kc * 8);
+      u32x4_t u = *(u32x4_t*)(sv + d * VT_PITCH + (slot << 4));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t m_lo = (2 * q < nvalid) ? 0x0000FFFFu : 0u;
+        const uint32_t m_hi = (2 * q + 1 < nvalid) ? 0xFFFF0000u : 0u;
+        u[q] &= (m_lo | m_hi);
+      }
+      *(u32x4_t*)(sv + d * VT_PITCH + (slot << 4)) = u;
+    }
+  };
+
+  int kaddr[2], vaddr[2];
+#pragma unroll
+  for (int bb = 0; bb < 2; ++bb) {
+    kaddr[bb] = (32 * bb + krow) << 7;
+    vaddr[bb] = (32 * bb + lr) * VT_PITCH;
+  }
+  const int kswz = (krow >> 1) & 7, vswz = (lr >> 1) & 7;
+
+  f32x16_t oacc[2][2];   // [d block][query block]
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) oacc[db][qb][v] = 0.f;
+  float mrun[2] = {NEG_BIG, NEG_BIG}, lrun[2] = {0.f, 0.f};
+  const float sc = p.scale * 1.4426950408889634f;
+
+  // 3-stage ring, two tiles in flight: the tile loop of the 2-stage form waited ~30 % of its wave cycles (SQ_WAIT_ANY) on the DMA it
+  // had issued one tile earlier — a tile's arithmetic is shorter than a loaded L2 round trip
+  if (ntiles > 0) dma_tile(0, 0);
+  if (ntiles > 1) dma_tile(1, 1);
+  if (ntiles > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile 0 landed (4 DMA instructions per wave and tile)
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (ntiles == 1 && 64 > klen) { fix_tail(0, 0); __syncthreads(); }
+
+  auto tile = [&](auto masked_tag, const int t) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    const int s = t % 3;
+    if (t + 2 < ntiles) dma_tile(t + 2, (t + 2) % 3);   // that stage was last read during tile t - 1: every wave is past its barrier
+    const char* sk = smem + s * STAGE_BYTES;
+    const char* sv = sk + KT_BYTES;
+    const int j0 = t << 6;
+
+    // ---- software pipeline inside the tile (r03 counters: VALU-active 54 % and MFMA-busy 30 % of the kernel's time, adding up instead
+    // of overlapping — both workgroups of a CU run the same phases in lockstep): the softmax of query block 0 is issued BETWEEN the
+    // QK^T MFMAs of block 1, the softmax of block 1 between the PV MFMAs of block 0.  An MFMA occupies the vector issue port for 8 of
+    // its 32 cycles and runs in the matrix pipe for the rest, so a wave's own VALU work fills the gaps.  sched_barrier(0) pins the
+    // interleave the source spells out (hipcc otherwise clusters the MFMAs).
+    f32x16_t sacc[2][2];   // [query block][key block]
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) sacc[qb][bb][v] = 0.f;
+    auto qk_step = [&](int qb, int i) {   // i = 4 bb + ks
+      const int bb = i >> 2, ks = i & 3;
+      const uint4 kf = *(const uint4*)(sk + kaddr[bb] + (((2 * ks + lh) ^ kswz) << 4));
+      sacc[qb][bb] = mfma32<DT>(kf, qf[qb][ks], sacc[qb][bb]);
+    };
+    uint4 pf[2][2][2];   // [query block][key block][k-step]
+    auto pv_step = [&](int qb, int i) {   // i = 4 db + 2 bb + s2
+      const int db = i >> 2, bb = (i >> 1) & 1, s2 = i & 1;
+      const uint4 vf = *(const uint4*)(sv + vaddr[db] + (((4 * bb + 2 * s2 + lh) ^ vswz) << 4));
+      oacc[db][qb] = mfma32<DT>(vf, pf[qb][bb][s2], oacc[db][qb]);
+    };
+    // softmax of one query block in 8 slices
+    float mx_[2], my_[2], mnew_[2], ls0_[2], ls1_[2], alpha_[2];
+    bool same_[2], dead_[2];
+    auto sm_step = [&](int qb, int i) {
+      const float scl = MASKED ? 1.0f : sc;
+      if (i == 0) {
+        if constexpr (MASKED) {
+          const int qi = q0 + 32 * qb + lr;
+          int jlim = klen;
+          if (p.causal) jlim = min(jlim, qi + p.causal_off + 1);
+          if (p.chunk > 0) jlim = min(jlim, ((qi + p.q_off) / p.chunk + 1) * p.chunk);
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+              const int j = j0 + 32 * bb + 16 * (v >> 3) + 8 * lh + (v & 7);
+              sacc[qb][bb][v] = (j < jlim) ? sacc[qb][bb][v] * sc : NEG_BIG;
+            }
+        }
+        float mx = fmaxf(fmaxf(sacc[qb][0][0], sacc[qb][0][1]), sacc[qb][0][2]);
+#pragma unroll
+        for (int v = 3; v + 1 < 16; v += 2) mx = fmaxf(fmaxf(mx, sacc[qb][0][v]), sacc[qb][0][v + 1]);
+        mx_[qb] = fmaxf(mx, sacc[qb][0][15]);
+      } else if (i == 1) {
+        float my = fmaxf(fmaxf(sacc[qb][1][0], sacc[qb][1][1]), sacc[qb][1][2]);
+#pragma unroll
+        for (int v = 3; v + 1 < 16; v += 2) my = fmaxf(fmaxf(my, sacc[qb][1][v]), sacc[qb][1][v + 1]);
+        float mx = fmaxf(fmaxf(mx_[qb], my), sacc[qb][1][15]);
+        const uint32_t u = __float_as_uint(mx);
+        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        mnew_[qb] = fmaxf(mrun[qb], mx * scl);
+        dead_[qb] = MASKED ? (mnew_[qb] <= 0.5f * NEG_BIG) : false;
+        alpha_[qb] = __builtin_amdgcn_exp2f(mrun[qb] - mnew_[qb]);
+        same_[qb] = __all(mnew_[qb] == mrun[qb]);
+        mrun[qb] = mnew_[qb];
+        ls0_[qb] = ls1_[qb] = 0.f;
+      } else if (i < 6) {   // 8 scores per slice: registers 8 (i - 2) & 15 .. of key block (i - 2) >> 1
+        const int bb = (i - 2) >> 1, v0 = ((i - 2) & 1) * 8;
+        const float nm = -mnew_[qb];
+#pragma unroll
+        for (int v = v0; v < v0 + 8; v += 2) {
+          const float e0 = __builtin_amdgcn_exp2f(fmaf(sacc[qb][bb][v], scl, nm));
+          const float e1 = __builtin_amdgcn_exp2f(fmaf(sacc[qb][bb][v + 1], scl, nm));
+          sacc[qb][bb][v] = e0;
+          sacc[qb][bb][v + 1] = e1;
+          ls0_[qb] += e0;
+          ls1_[qb] += e1;
+        }
+        // the partial row sums are "redefined" here: MachineSink otherwise moves the whole slice (its results are only used after the
+        // rescale branch of slice 7) below that branch, out of the MFMA gaps it was written into
+        asm volatile("" : "+v"(ls0_[qb]), "+v"(ls1_[qb]));
+      } else if (i == 6) {
+        if constexpr (MASKED) {
+          if (dead_[qb]) {
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+              for (int v = 0; v < 16; ++v) sacc[qb][bb][v] = 0.f;
+            ls0_[qb] = ls1_[qb] = 0.f;
+          }
+        }
+        lrun[qb] = fmaf(lrun[qb], alpha_[qb], ls0_[qb] + ls1_[qb]);
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            uint4 f;
+            f.x = pack2<DT>(sacc[qb][bb][8 * s2 + 0], sacc[qb][bb][8 * s2 + 1]);
+            f.y = pack2<DT>(sacc[qb][bb][8 * s2 + 2], sacc[qb][bb][8 * s2 + 3]);
+            f.z = pack2<DT>(sacc[qb][bb][8 * s2 + 4], sacc[qb][bb][8 * s2 + 5]);
+            f.w = pack2<DT>(sacc[qb][bb][8 * s2 + 6], sacc[qb][bb][8 * s2 + 7]);
+            pf[qb][bb][s2] = f;
+          }
+      } else {
+        if (!same_[qb]) {
+#pragma unroll
+          for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) oacc[db][qb][v] *= alpha_[qb];
+        }
+      }
+    };
+    // phase A: S^T of query block 0
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qk_step(0, i);
+    __builtin_amdgcn_sched_barrier(0);
+    // phase B: S^T of query block 1 under the softmax of block 0
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      qk_step(1, i);
+      sm_step(0, i);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // phase C: O^T of query block 0 under the softmax of block 1
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      pv_step(0, i);
+      sm_step(1, i);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // phase D: O^T of query block 1
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pv_step(1, i);
+
+    // this wave's share of tile t + 1 has landed (tile t + 2's four DMA instructions may still be in flight)
+    if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 2 == ntiles && ((t + 1) << 6) + 64 > klen) {   // wave-uniform: the next tile is the tail tile
+      fix_tail(t + 1, (t + 1) % 3);
+      __syncthreads();
+    }
+  };
+
+  int nfull = 0;
+  {
+    int jmin = klen;
+    if (p.causal) jmin = min(jmin, q0 + p.causal_off + 1);
+    if (p.chunk > 0) jmin = min(jmin, ((q0 + p.q_off) / p.chunk + 1) * p.chunk);
+    nfull = min(max(jmin, 0) >> 6, ntiles);
+  }
+  int t = 0;
+  for (; t < nfull; ++t) tile(std::false_type{}, t);
+  for (; t < ntiles; ++t) tile(std::true_type{}, t);
+
+  // ---- finalize: lane holds query 32 qb + lr, d = 32 db + 8 (v >> 2) + 4 lh + (v & 3)
+  uint16_t* O = (uint16_t*)p.out + (int64_t)b * p.o_bs + h * 64;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    float l = lrun[qb];
+    l += __shfl_xor(l, 32, 64);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    const int i = q0 + 32 * qb + lr;
+    if (i >= p.Tq) continue;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        uint2 u;
+        u.x = pack2<DT>(oacc[db][qb][4 * g4 + 0] * inv, oacc[db][qb][4 * g4 + 1] * inv);
+        u.y = pack2<DT>(oacc[db][qb][4 * g4 + 2] * inv, oacc[db][qb][4 * g4 + 3] * inv);
+        *(uint2*)(O + (int64_t)i * p.ldo + 32 * db + 8 * g4 + 4 * lh) = u;
+      }
+  }
+}
+
 }  // namespace
 
 extern "C" int cv_attention(const cv_attn_params* pp, void* stream) {
@@ -657,8 +951,24 @@ extern "C" int cv_attention(const cv_attn_params* pp, void* stream) {
   const int forced = fe ? atoi(fe) : 0;
   const int64_t wgs4 = (int64_t)p.H * ((p.Tq + 127) / 128) * p.B;
   const bool two = forced == 2 || (forced != 4 && wgs4 < 256);
-  const char* me = getenv("CV_ATTN_MFMA");   // 32 (default): the 32x32x16 form; 16: the 16x16x32 form (kept as its cross-check)
-  const bool m32 = !(me && atoi(me) == 16);
+  // CV_ATTN_MFMA selects the alternative forms built and measured in round 3 (all tested against torch, tests/test_attention_gpu.py):
+  //   16 (default) the 16x16x32 form above;
+  //   32 the same tiling on 32x32x16 MFMAs (half the MFMA issue slots, one cross-lane step per row max): 58.2 vs 57.0 us;
+  //   64 64 queries per wave, K / V^T by LDS-DMA into a 3-stage ring, the softmax of one query block issued between the MFMAs of the
+  //      other (no bias operand): 57.0 - 58.2 us.
+  // At the estimator's batch-8 shape (16 x 8 heads x T = 1000) all three take 57 - 58 us: the time is ~410 VALU + 32 MFMA issued per 64
+  // queries x 64 keys (SQ_INSTS_VALU identical in every form) and ~30 % of wave cycles waiting, not the tile schedule.
+  const char* me = getenv("CV_ATTN_MFMA");
+  const int mf = me ? atoi(me) : 0;
+  if (!p.bias && p.Tk >= 8 && p.vt_ld >= 8 && mf == 64) {
+    dim3 grid(p.H, (p.Tq + 255) / 256, p.B);
+    const size_t lds64 = 3 * STAGE_BYTES;
+    if (p.dtype == CV_BF16) hipLaunchKernelGGL((attn64_kernel<CV_BF16>), grid, dim3(256), lds64, st, p);
+    else hipLaunchKernelGGL((attn64_kernel<CV_F16>), grid, dim3(256), lds64, st, p);
+    CV_CHECK_LAUNCH();
+    return CV_OK;
+  }
+  const bool m32 = mf == 32;
   if (two) {
     dim3 grid(p.H, (p.Tq + 63) / 64, p.B);
     if (m32) {

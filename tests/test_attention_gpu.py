@@ -37,7 +37,7 @@ def _ref(q, k, v, scale, klen=None, chunk=0, causal=False, causal_off=0, bias=No
     (2, 14, 2, 107, 107, "causal"), (1, 8, 8, 100, 100, "bias"), (1, 4, 4, 1000, 1000, "plain"),
 ])
 @pytest.mark.parametrize("waves", ["4", "2"])
-@pytest.mark.parametrize("mfma", ["32", "16"])
+@pytest.mark.parametrize("mfma", ["64", "32", "16"])
 def test_attention_vs_torch(dt, B, H, Hkv, Tq, Tk, mode, waves, mfma, monkeypatch):
     """Both workgroup shapes (128 queries / 4 waves: the batch-8 grids; 64 queries / 2 waves: grids that would not fill the chip) and
     both MFMA forms (32x32x16: the default; 16x16x32: its cross-check)."""
@@ -88,7 +88,7 @@ def test_attention_vs_torch(dt, B, H, Hkv, Tq, Tk, mode, waves, mfma, monkeypatc
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("with_bias", [False, True])
-@pytest.mark.parametrize("mfma", ["32", "16"])
+@pytest.mark.parametrize("mfma", ["64", "32", "16"])
 def test_fully_masked_query_rows_are_zero(dt, with_bias, mfma, monkeypatch):
     """A negative causal_off leaves the first queries without any visible key: those rows must come out as zeros (every masked
     score used to equal the running "max", so exp2(0) = 1 gave them mean(V) of the loaded tiles); the other rows are unaffected."""
@@ -122,7 +122,7 @@ def test_fully_masked_query_rows_are_zero(dt, with_bias, mfma, monkeypatch):
 
 @pytest.mark.parametrize("dt,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
 @pytest.mark.parametrize("jump", [3.0, 7.5, 8.5, 40.0])
-@pytest.mark.parametrize("mfma", ["32", "16"])
+@pytest.mark.parametrize("mfma", ["64", "32", "16"])
 def test_online_softmax_rescale_branch(dt, tol, jump, mfma, monkeypatch):
     """The tile step rescales its output accumulators only when some query's running max moved (wave-uniform branch).  A rare,
     data-dependent branch needs an input that FORCES it at chosen tiles: one key per tile (3, 6, 9) whose score exceeds everything
