@@ -37,6 +37,11 @@ def attn():
                       q_bs=T * 2 * inner, ldq=2 * inner, k_bs=T * 2 * inner, ldk=2 * inner, vt_ld=Tp, o_bs=T * inner, ldo=inner)
 def tail():
     for p in ps: ops.tblock_tail(p)
+def tail_head():   # tail of block i + head of block i + 1 in one launch (cv_tblock_tail_head): what blocks 0..2 of every group of 4 run
+    for i, p in enumerate(ps):
+        q = ps[(i + 1) % len(ps)]
+        p.g1, p.b1n, p.wqkv_p = q.g1, q.b1n, q.wqkv_p
+        ops.tblock_tail_head(p)
 
 def timed(fn, flop):
     fn(); torch.cuda.synchronize()
@@ -52,7 +57,8 @@ def timed(fn, flop):
 
 rows = R * T
 for name, fn, flop in (("head", head, 2.0 * rows * 256 * 1536), ("attention", attn, 4.0 * R * H * T * T * 64),
-                       ("tail", tail, 2.0 * rows * (512 * 256 + 2 * 256 * 1024))):
+                       ("tail", tail, 2.0 * rows * (512 * 256 + 2 * 256 * 1024)),
+                       ("tail+head", tail_head, 2.0 * rows * (512 * 256 + 2 * 256 * 1024 + 256 * 1536))):
     us, tf = timed(fn, flop)
     ws["x32"].normal_()   # the tail updates x in place: keep it bounded
     print(f"{name:10s} R={R} T={T}: {us:7.1f} us per call  {tf:6.0f} TFLOP/s", flush=True)
