@@ -542,7 +542,8 @@ class CosyVoice2Model:
     def _tts_batches_shared(self, batches, to_host):
         llm_stream = self.llm_context.stream if hasattr(self.llm_context, "stream") else torch.cuda.Stream()
         pending, pending_b = None, None
-        for b in list(batches) + [None]:
+        import itertools
+        for b in itertools.chain(batches, [None]):   # lazily: a batch takes its buffers when its turn comes
             toks = None
             if b is not None:
                 with torch.cuda.stream(llm_stream):
