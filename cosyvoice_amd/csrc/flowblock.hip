@@ -223,21 +223,41 @@ __device__ __forceinline__ void head_body(const cv_tblock_params& p, const char*
     if (!vpart) {
 #pragma unroll
       for (int kq = 0; kq < 4; ++kq) { compute(s[kq], kq, false); ld(s[kq], st * 4 + kq + NS); }
-      // D rows = output column: lane holds row m = 16 i + lq, columns n .. n + 3
+      // D rows = output column: lane (lq, lg) holds row m = 16 i + lq, columns 4 lg ..+3 of each of the 4 column tiles j.  The four lanes
+      // lg = 0..3 of a row exchange their pieces (4 x 4 transpose over (lane lg, tile j): permlane32_swap on bit 1, permlane16_swap on
+      // bit 0) so that lane lg owns the 16 columns of tile lg = 32 contiguous bytes: two 16-byte stores instead of four 8-byte ones, 64
+      // contiguous bytes per row and instruction instead of 32 (the stores were 10 of the head's 27 us, r02 ablation; cdna guide T21).
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int t = t0 + 16 * i + lq;
+        uint32_t w[4][2];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const uint2 u = pack4<DT>(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-          if (ABL & 1) { asm volatile("" :: "v"(u.x), "v"(u.y)); continue; }
-          __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{u.x, u.y}, qk_rs, (t * p.ldqk + (tile0 + j) * 16 + 4 * lg) * 2, 0, 0);
+          w[j][0] = u.x; w[j][1] = u.y;
         }
+        if (ABL & 1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(w[j][0]), "v"(w[j][1]));
+          continue;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const auto a = __builtin_amdgcn_permlane32_swap(w[0][k], w[2][k], false, false);
+          const auto b = __builtin_amdgcn_permlane32_swap(w[1][k], w[3][k], false, false);
+          const auto c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+          const auto d = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+          w[0][k] = c[0]; w[1][k] = c[1]; w[2][k] = d[0]; w[3][k] = d[1];
+        }
+        const int off = (t * p.ldqk + (tile0 + lg) * 16) * 2;
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{w[0][0], w[0][1], w[1][0], w[1][1]}, qk_rs, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{w[2][0], w[2][1], w[3][0], w[3][1]}, qk_rs, off + 16, 0, 0);
       }
     } else {
 #pragma unroll
       for (int kq = 0; kq < 4; ++kq) { compute(s[kq], kq, true); ld(s[kq], st * 4 + kq + NS); }
-      // D rows = frame: lane holds V^T row (head * 64 + d) = column tile * 16 + lq, frames t .. t + 3
+      // D rows = frame: lane holds V^T row (head * 64 + d) = column tile * 16 + lq, frames t .. t + 3 (the 4 x 4 exchange of the [Q | K]
+      // stores was tried here too, over (lane lg, row tile i): 25.9 vs 25.1 us, no gain — the V^T rows are already 32-byte runs per lane group)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int vrow = (tile0 + j) * 16 + lq - 2 * TB_INNER;
@@ -919,8 +939,8 @@ extern "C" int cv_tblock_head(const cv_tblock_params* pp, void* stream) {
   const cv_tblock_params p = *pp;
   if (int rc = check_common(p)) return rc;
   if (!p.g1 || !p.b1n || !p.wqkv_p || !p.qk || !p.vt) return CV_ERR_ARG;
-  if ((p.ldqk & 3) || (p.vt_ld & 3) || p.vt_ld < p.T || ((uintptr_t)p.qk & 7) || ((uintptr_t)p.vt & 7) || ((uintptr_t)p.wqkv_p & 15))
-    return CV_ERR_ARG;
+  if ((p.ldqk & 7) || (p.vt_ld & 3) || p.vt_ld < p.T || ((uintptr_t)p.qk & 15) || ((uintptr_t)p.vt & 7) || ((uintptr_t)p.wqkv_p & 15))
+    return CV_ERR_ARG;   // [Q | K] rows are written with 16-byte stores
   if ((int64_t)p.T * p.ldqk * 2 >= (1ll << 31) || (int64_t)TB_INNER * p.vt_ld * 2 >= 0x7FFFFFF0ll) return CV_ERR_ARG;   // 32-bit buffer offsets
   hipStream_t st = (hipStream_t)stream;
   if (p.dtype == CV_BF16) dispatch_head<CV_BF16>(p, st);
@@ -955,7 +975,7 @@ extern "C" int cv_tblock_tail_head(const cv_tblock_params* pp, void* stream) {
     return CV_ERR_ARG;
   if (p.out_act) return CV_ERR_ARG;   // the 16-bit copy belongs to the LAST block of a group, which has no following head
   if (!p.g1 || !p.b1n || !p.wqkv_p || !p.qk || !p.vt) return CV_ERR_ARG;
-  if ((p.ldqk & 3) || (p.vt_ld & 3) || p.vt_ld < p.T || ((uintptr_t)p.qk & 7) || ((uintptr_t)p.vt & 7) || ((uintptr_t)p.wqkv_p & 15))
+  if ((p.ldqk & 7) || (p.vt_ld & 3) || p.vt_ld < p.T || ((uintptr_t)p.qk & 15) || ((uintptr_t)p.vt & 7) || ((uintptr_t)p.wqkv_p & 15))
     return CV_ERR_ARG;
   if ((int64_t)p.T * p.ldqk * 2 >= (1ll << 31) || (int64_t)TB_INNER * p.vt_ld * 2 >= 0x7FFFFFF0ll || (int64_t)p.T * p.ldx * 4 >= (1ll << 31))
     return CV_ERR_ARG;   // 32-bit buffer offsets

@@ -163,7 +163,7 @@ typedef struct cv_tblock_params {
   /* head */
   const float* g1; const float* b1n;      /* norm1 weight / bias [C] */
   const void* wqkv_p;                     /* packed [Wq; Wk; Wv] (3 * inner rows, K = C), no bias */
-  void* qk; int32_t ldqk;                 /* [R * T][ldqk] */
+  void* qk; int32_t ldqk;                 /* [R * T][ldqk]; 16-byte aligned, ldqk a multiple of 8 (rows are written with 16-byte stores) */
   void* vt; int32_t vt_ld;                /* [R][inner / 64][64][vt_ld] */
   /* tail */
   const void* ao; int32_t ldao;           /* attention output [R * T][ldao] or NULL */
