@@ -16,6 +16,8 @@
 
 namespace {
 
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
 template <int DT> struct ElemSize { static constexpr int value = (DT == CV_F32) ? 4 : 2; };
 
 // LDS tile image: plain row-major, 128 bytes (8 x 16-byte chunks) per row, chunk position XOR-swizzled by (row>>1)&7.
@@ -63,7 +65,7 @@ __device__ __forceinline__ void store_split4(void* base, int64_t idx, float a, f
   *(uint2*)(g + 16) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
 }
 
-template <int DT, int MT, int NT>
+template <int DT, int MT, int NT, bool VEC_ONLY = false>   // VEC_ONLY: the caller guarantees N % 4 == 0, row-major output, no SwiGLU (conv_win_kernel)
 __device__ __forceinline__ void gemm_epilogue(const cv_gemm_params& p, f32x4_t (&acc)[MT][NT], int m0, int n0, int wave_m, int wave_n,
                                               int lane, int z, int z0, int z1) {
   constexpr int ES = ElemSize<DT>::value;
@@ -76,7 +78,7 @@ __device__ __forceinline__ void gemm_epilogue(const cv_gemm_params& p, f32x4_t (
   const int64_t res_off = z0 * p.res_bs0 + z1 * p.res_bs1;
   float* o32 = p.out_f32 ? p.out_f32 + (z0 * p.o32_bs0 + z1 * p.o32_bs1) : nullptr;
   char* oact = p.out_act ? (char*)p.out_act + (z0 * p.oa_bs0 + z1 * p.oa_bs1) * ES : nullptr;
-  const bool vec = ((p.N & 3) == 0) && (p.act != CV_ACT_SWIGLU) && (p.out_mode == CV_OUT_ROWMAJOR);
+  const bool vec = VEC_ONLY || (((p.N & 3) == 0) && (p.act != CV_ACT_SWIGLU) && (p.out_mode == CV_OUT_ROWMAJOR));
 
   if (vec) {
     const bool has_res = p.res != nullptr, has_res2 = p.res2 != nullptr;
@@ -125,8 +127,13 @@ __device__ __forceinline__ void gemm_epilogue(const cv_gemm_params& p, f32x4_t (
         const float v3 = (acc[i][j][3] + b4[j].w + r4[j].w) * p.out_scale;
         if (o32) *(float4*)(o32 + (int64_t)orow[i] * p.ldo32 + nbj[j]) = make_float4(v0, v1, v2, v3);
         if (oact) {
-          const float a0 = apply_act(p.act, v0, ap4[j].x, p.act_slope), a1 = apply_act(p.act, v1, ap4[j].y, p.act_slope);
-          const float a2 = apply_act(p.act, v2, ap4[j].z, p.act_slope), a3 = apply_act(p.act, v3, ap4[j].w, p.act_slope);
+          float a0, a1, a2, a3;
+          if (VEC_ONLY && p.act == CV_ACT_SNAKE) {   // the HiFT convs: no 7-way switch per element in a 64-element unrolled epilogue
+            a0 = act_snake(v0, ap4[j].x); a1 = act_snake(v1, ap4[j].y); a2 = act_snake(v2, ap4[j].z); a3 = act_snake(v3, ap4[j].w);
+          } else {
+            a0 = apply_act(p.act, v0, ap4[j].x, p.act_slope); a1 = apply_act(p.act, v1, ap4[j].y, p.act_slope);
+            a2 = apply_act(p.act, v2, ap4[j].z, p.act_slope); a3 = apply_act(p.act, v3, ap4[j].w, p.act_slope);
+          }
           if (DT == CV_F32 && (p.x3_flags & 4)) store_split4(oact, (int64_t)orow[i] * p.ldoa + nbj[j], a0, a1, a2, a3);
           else store_act4<DT>(oact, (int64_t)orow[i] * p.ldoa + nbj[j], a0, a1, a2, a3);
         }
@@ -134,6 +141,7 @@ __device__ __forceinline__ void gemm_epilogue(const cv_gemm_params& p, f32x4_t (
     }
     return;
   }
+  if constexpr (VEC_ONLY) return;
 
   // ---- general path (N % 4 != 0, SwiGLU pairs, QKV split): correctness first, used by a handful of small launches
 #pragma unroll
@@ -590,11 +598,181 @@ int launch_ring(const cv_gemm_params& p, hipStream_t st) {
   return CV_OK;
 }
 
+// ================================================================================================================
+// conv_win_kernel: stride-1 Conv1d on the bf16x3 path with both operands pre-split (the HiFT / BigVGAN ResBlock convs: 91 % of the
+// vocoder's time on gemm_kernel<64,64,X3,PS>).  The implicit-im2col GEMM above re-fetches every activation row once per tap and
+// once per tile column through global loads -> registers -> LDS and synchronises twice per 32-deep K tile (12 MFMAs per wave): it
+// is bound by operand staging (~6-15 B/clk/CU), not MFMA (0.10 of the bf16 peak issued, profiles/r03_hift_*).  Here a workgroup
+// keeps the activation WINDOW of its rows — BM + (taps-1)*dilation rows x 64 channels, pre-split: 256 B per row — in LDS once per
+// 64-channel chunk (LDS-DMA, XOR-swizzled on the source address) and every tap reads its A fragments from that image at a shifted
+// row; the weights never touch LDS: each wave streams the fragments of its own 64 output columns L2 -> VGPR through a buffer
+// descriptor (the (tap, chunk, k-step) offset is an SGPR), double-buffered one 32-deep k-step ahead.  Per k-step a wave issues
+// 8 ds_read_b128 + 8 buffer loads for 48 MFMAs (wave tile 64 x 64) and a workgroup synchronises twice per CHUNK, not per K tile.
+// Summation order per output: chunk-major, then tap, then k-step, cross terms before hi*hi — the same for every tile shape, so a
+// conv's result does not depend on the batch size or on the tile the dispatcher picks.
+template <int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_win_kernel(const cv_gemm_params p, const int win_rows) {
+  constexpr int NW = WM * WN, MT = 4, NT = 4, BM = 64 * WM, BN = 64 * WN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wid / WN, wave_n = wid % WN;
+  const int lq = lane & 15, lg = lane >> 4;
+
+  const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
+  int tile_m, tile_n;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    tile_n = id % ntiles; tile_m = id / ntiles;   // column tiles of one window back to back on one XCD
+    (void)mtiles;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int z = blockIdx.z;
+  const int z1 = z / p.batch_inner, z0 = z - z1 * p.batch_inner;
+  const char* Ab = (const char*)p.A + (z0 * p.a_bs0 + z1 * p.a_bs1) * 4;
+  const char* Wb = (const char*)p.W + (z0 * p.w_bs0 + z1 * p.w_bs1) * 4;
+  const int ktaps = p.K / p.cin, nchunks = p.cin >> 6;
+  const char* zero = (const char*)&g_zero16;
+
+  // ---- window loader: LDS-DMA, one wave instruction = 1 KiB = 4 window rows x 16 chunk slots; slot s of row r holds global chunk s ^ (r & 15)
+  const int wr_in = lane >> 4, wslot = lane & 15;
+  const int ngroups = (win_rows + 3) >> 2;
+  auto load_window = [&](int c) {
+    for (int g = wid; g < ngroups; g += NW) {
+      const int w = g * 4 + wr_in;
+      const int arow = m0 + p.tap_base + w;
+      const bool ok = (w < win_rows) && (arow >= 0) && (arow < p.a_rows);
+      const char* src = ok ? Ab + ((int64_t)arow * p.lda + c * 64) * 4 + ((wslot ^ (w & 15)) << 4) : zero;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(smem + g * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- weight stream: lane = output column (lq) x 8-value group (lg) of the 32-deep k-step; [8 hi | 8 lo] = 32 contiguous bytes
+  const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, (int)min((int64_t)p.N * p.ldw * 4, (int64_t)0x7FFFFFFF), 0x00020000);
+  int woff[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = min(n0 + (wave_n * NT + j) * 16 + lq, p.N - 1);
+    woff[j] = (n * p.ldw + lg * 8) * 4;
+  }
+  u32x4_t wh[2][NT], wl[2][NT];
+  auto load_w = [&](int set, int c, int t, int ks) {
+    const int so = (t * p.cin + c * 64 + ks * 32) * 4;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      wh[set][j] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, woff[j], so, 0);
+      wl[set][j] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, woff[j] + 16, so, 0);
+    }
+  };
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int rbase = wave_m * (MT * 16) + lq;   // window row of this lane's A fragment row at tap 0, row tile 0
+  auto step = [&](int set, int t, int ks) {
+    uint4 ah[MT], al[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int row = rbase + i * 16 + t * p.tap_step;
+      const int off = (row << 8) + ((((lg << 1) ^ (row & 15)) << 4) ^ (ks << 7));   // slot = chunk ^ (row & 15), chunk = ks*8 + lg*2 + {hi 0, lo 1}
+      ah[i] = *(const uint4*)(smem + off);
+      al[i] = *(const uint4*)(smem + (off ^ 16));
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const uint4 bh = bitcast<uint4>(wh[set][j]), bl = bitcast<uint4>(wl[set][j]);
+        acc[i][j] = mfma_block<CV_BF16>(bl, ah[i], acc[i][j]);
+        acc[i][j] = mfma_block<CV_BF16>(bh, al[i], acc[i][j]);
+        acc[i][j] = mfma_block<CV_BF16>(bh, ah[i], acc[i][j]);
+      }
+  };
+
+  load_w(0, 0, 0, 0);
+  for (int c = 0; c < nchunks; ++c) {
+    load_window(c);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < ktaps; ++t) {
+      // sched_barrier(0): left alone, hipcc sinks each refill to just before its first use and the prefetch distance collapses to zero
+      load_w(1, c, t, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      step(0, t, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < ktaps) load_w(0, c, t + 1, 0);
+      else if (c + 1 < nchunks) load_w(0, c + 1, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      step(1, t, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (c + 1 < nchunks) __syncthreads();   // every wave is done with this chunk's image before the next one lands
+  }
+  gemm_epilogue<CV_F32, MT, NT, true>(p, acc, m0, n0, wave_m, wave_n, lane, z, z0, z1);
+}
+
+// CV_CONV_WIN=1 opts the qualifying convs in (default: gemm_kernel); CV_CONV_WIN_SHAPE=WMxWN forces one workgroup shape.  Both are read
+// per call.  Measured (tools/hift_conv_bench.py, profiles/r03_hift_conv_bench.log): per tap the window kernel's MFMA loop is
+// faster (11.4 vs 14.4 us per tap at 8 x 60 000 x 64, 17 % at 8 x 20 000 x 128 k = 11) but its window load and epilogue are not overlapped with
+// compute (131 vs 65 us of fixed time per conv at 8 x 60 000 x 64: the conv's activation traffic alone is 49 us at 5 TB/s), so it wins only
+// for C >= 128 with k >= 7 on large grids and loses everywhere else — not the default.
+constexpr int CONV_WIN_LDS_MAX = 80 * 1024;   // two workgroups per CU
+
+template <int WM, int WN>
+int launch_conv_win(const cv_gemm_params& p, hipStream_t st, int halo) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  const int win_rows = BM + halo;
+  const size_t lds = (size_t)((win_rows + 3) & ~3) * 256;
+  static PerDeviceOnce once;
+  once.run([&] { hipFuncSetAttribute((const void*)conv_win_kernel<WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_WIN_LDS_MAX); });
+  dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, p.batch);
+  hipLaunchKernelGGL((conv_win_kernel<WM, WN>), grid, dim3(64 * WM * WN), lds, st, p, win_rows);
+  CV_CHECK_LAUNCH();
+  return CV_OK;
+}
+
+// returns CONV_WIN_NO when the launch does not qualify (the caller falls through to gemm_kernel)
+constexpr int CONV_WIN_NO = 1;
+int dispatch_conv_win(const cv_gemm_params& p, hipStream_t st) {
+  int force_wm = 0, force_wn = 0;
+  if (const char* e = getenv("CV_CONV_WIN"); !e || atoi(e) != 1) return CONV_WIN_NO;
+  if (const char* s = getenv("CV_CONV_WIN_SHAPE"); s && s[0] >= '1' && s[0] <= '4' && s[1] == 'x' && s[2] >= '1' && s[2] <= '2') { force_wm = s[0] - '0'; force_wn = s[2] - '0'; }
+  if (p.cin == p.K || (p.x3_flags & 3) != 3 || p.a_row_stride != 1 || p.tap_step <= 0) return CONV_WIN_NO;
+  if ((p.cin & 63) || (p.N & 63) || p.act == CV_ACT_SWIGLU || p.out_mode != CV_OUT_ROWMAJOR) return CONV_WIN_NO;
+  if ((int64_t)p.N * p.ldw * 4 > 0x7FFFFFFF) return CONV_WIN_NO;
+  const int halo = (p.K / p.cin - 1) * p.tap_step;
+  int wm, wn = (p.N >= 128) ? 2 : 1;
+  if (force_wm) { wm = force_wm == 3 ? 2 : force_wm; wn = min(force_wn, wn); }
+  else {
+    // four waves per workgroup (128 x 128 or 256 x 64) when that still gives every CU a workgroup; else halve the rows, then the columns
+    wm = 4 / wn;
+    auto wgs = [&](int a, int b) { return (long long)((p.M + 64 * a - 1) / (64 * a)) * ((p.N + 64 * b - 1) / (64 * b)) * p.batch; };
+    while (wm > 1 && wgs(wm, wn) < 256) wm >>= 1;
+    if (wn > 1 && wgs(wm, wn) < 256) wn = 1;
+  }
+  while (wm > 1 && (size_t)((64 * wm + halo + 3) & ~3) * 256 > (size_t)CONV_WIN_LDS_MAX) wm >>= 1;
+  if ((size_t)((64 * wm + halo + 3) & ~3) * 256 > (size_t)CONV_WIN_LDS_MAX) return CONV_WIN_NO;
+  if (wm == 4 && wn == 1) return launch_conv_win<4, 1>(p, st, halo);
+  if (wm == 2 && wn == 2) return launch_conv_win<2, 2>(p, st, halo);
+  if (wm == 2 && wn == 1) return launch_conv_win<2, 1>(p, st, halo);
+  if (wm == 1 && wn == 2) return launch_conv_win<1, 2>(p, st, halo);
+  if (wm == 1 && wn == 1) return launch_conv_win<1, 1>(p, st, halo);
+  return CONV_WIN_NO;
+}
+
 // CV_GEMM_TILE=0|1|2|3 (128x128 | 128x64 | 64x64 | 128x128 LDS-DMA ring) overrides the heuristic: tuning aid only
 static int g_tile_override = -2;
 
 // fp32 tensors, bf16x3 products: the two register-staged tiles only
 int dispatch_x3(const cv_gemm_params& p, hipStream_t st) {
+  if (const int rc = dispatch_conv_win(p, st); rc != CONV_WIN_NO) return rc;
   const long long t12864 = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * p.batch;
   const bool big = p.act == CV_ACT_SWIGLU || (p.K > 512 && t12864 >= 768);
   if ((p.x3_flags & 3) == 3) {   // both operands pre-split

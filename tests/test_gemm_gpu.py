@@ -124,3 +124,53 @@ def test_tall_gemm_tile_plain_and_swiglu(dt):
     torch.cuda.synchronize()
     assert _rel(o32, x.float() @ W.float().t() + res) < TOL[dt] * 0.5
     assert _rel(h, F.silu(x.float() @ g.float().t()) * (x.float() @ u.float().t())) < TOL[dt]
+
+
+def _unsplit(t):
+    """pre-split fp32-sized storage (.., C) -> the fp32 values hi + lo it stands for."""
+    raw = t.contiguous().view(torch.int16).reshape(*t.shape[:-1], t.shape[-1] // 8, 16)
+    hi, lo = raw[..., :8].contiguous().view(torch.bfloat16), raw[..., 8:].contiguous().view(torch.bfloat16)
+    return (hi.float() + lo.float()).reshape(t.shape)
+
+
+@pytest.mark.parametrize("shape", ["auto", "4x1", "2x2", "2x1", "1x2", "1x1"])
+@pytest.mark.parametrize("Cin,Cout,k,dil,T,B", [(64, 64, 3, 1, 1000, 2), (64, 64, 11, 5, 777, 1), (128, 128, 7, 3, 601, 2),
+                                                (256, 256, 11, 5, 500, 1), (256, 256, 3, 1, 130, 3), (128, 64, 7, 1, 70, 2), (64, 192, 3, 3, 257, 1)])
+def test_conv_window_kernel_presplit(Cin, Cout, k, dil, T, B, shape, monkeypatch):
+    """conv_win_kernel (stride-1 bf16x3 convs on pre-split operands: activation window in LDS, weights streamed L2 -> VGPR) against torch
+    fp32, and against gemm_kernel on the same launch (the default; the window kernel is opt-in, CV_CONV_WIN=1): both the fp32 output and the pre-split snake output, every
+    workgroup shape, ragged row / column tails, zero padding on both sides, residual + scale epilogue."""
+    from cosyvoice_amd import ops, _lib as L
+    from cosyvoice_amd.hift import _presplit
+    torch.manual_seed(11)
+    dev = "cuda"
+    x = torch.randn(B, T, Cin)
+    w = torch.randn(Cout, Cin, k) / (Cin * k) ** 0.5
+    bias = torch.randn(Cout, device=dev)
+    alpha = torch.rand(Cout, device=dev) + 0.5
+    res = torch.randn(B, T, Cout, device=dev)
+    pad = (k * dil - dil) // 2
+    xs = _presplit(x.reshape(B * T, Cin)).view(torch.float32).reshape(B, T, Cin).to(dev)
+    Wp = w.permute(0, 2, 1).reshape(Cout, k * Cin).contiguous()
+    Ws = _presplit(Wp).view(torch.float32).to(dev)
+    xv, wv = _unsplit(xs.cpu()).to(dev), _unsplit(Ws.cpu()).to(dev).reshape(Cout, k, Cin).permute(0, 2, 1)
+    ref = (F.conv1d(xv.double().transpose(1, 2), wv.double(), bias.double(), dilation=dil, padding=pad).transpose(1, 2) + res.double()) * 0.5
+    sn = ref + (1.0 / (alpha.double() + 1e-9)) * torch.sin(ref * alpha.double()) ** 2
+    outs = {}
+    for win in ("1", "0"):
+        monkeypatch.setenv("CV_CONV_WIN", win)
+        if shape != "auto":
+            monkeypatch.setenv("CV_CONV_WIN_SHAPE", shape)
+        o32 = torch.full((B, T, Cout), float("nan"), device=dev)
+        oa = torch.full((B, T, Cout), float("nan"), device=dev)
+        ops.conv1d_cl(xs, Ws, k, dilation=dil, pad_left=pad, bias=bias, res=res, out_scale=0.5, act=ops.ACT_SNAKE, act_param=alpha,
+                      out_f32=o32, out_act=oa, dtype=L.CV_F32X3, x3_flags=7)
+        torch.cuda.synchronize()
+        outs[win] = (o32.clone(), _unsplit(oa.cpu()).to(dev))
+        # bf16x3 drops the lo*lo term: relative 2^-16 per product, fp32 accumulation
+        assert (o32.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+        assert (outs[win][1].double() - sn).abs().max().item() < 5e-5 * max(1.0, sn.abs().max().item())
+    d = (outs["1"][0] - outs["0"][0]).abs().max().item()
+    assert d < 2e-6 * max(1.0, ref.abs().max().item())
+    if Cin == 64:   # one channel chunk: same summation order as the K-tile loop
+        assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])
