@@ -51,8 +51,8 @@ __device__ __forceinline__ void store_act4(void* base, int64_t idx, float a, flo
 
 // fp32 values in the PRE-SPLIT storage of the bf16x3 path: every aligned group of 8 values (32 bytes) holds [8 x bf16 hi | 8 x bf16 lo]
 // (hi = bf16(v), lo = bf16(v - hi): exactly what the consumer's LDS store would compute, computed once by the producer instead of
-// once per tap and per tile column by every consumer).  A lane holds 4 consecutive values (idx % 4 == 0): two 8-byte stores.
-__device__ __forceinline__ void store_split4(void* base, int64_t idx, float a, float b, float c, float d) {
+// once per tap and per tile column by every consumer).  A lane holds 4 consecutive values (idx % 4 == 0) = half a group.
+__device__ __forceinline__ void split_pack4(float a, float b, float c, float d, uint2& hi, uint2& lo) {
   const float f[4] = {a, b, c, d};
   uint16_t h[4], l[4];
 #pragma unroll
@@ -60,9 +60,8 @@ __device__ __forceinline__ void store_split4(void* base, int64_t idx, float a, f
     h[j] = Elem16<CV_BF16>::from_f32(f[j]);
     l[j] = Elem16<CV_BF16>::from_f32(f[j] - Elem16<CV_BF16>::to_f32(h[j]));
   }
-  char* g = (char*)base + (idx & ~(int64_t)7) * 4 + ((idx >> 2) & 1) * 8;   // group base + which half of the group this lane fills
-  *(uint2*)g = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-  *(uint2*)(g + 16) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+  hi = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+  lo = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
 }
 
 template <int DT, int MT, int NT, bool VEC_ONLY = false>   // VEC_ONLY: the caller guarantees N % 4 == 0, row-major output, no SwiGLU (conv_win_kernel)
@@ -120,22 +119,37 @@ __device__ __forceinline__ void gemm_epilogue(const cv_gemm_params& p, f32x4_t (
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        if (!rok[i] || nbj[j] >= p.N) continue;
+        const bool live = rok[i] && nbj[j] < p.N;   // uniform over the lane pairs (lg, lg ^ 1) of the pre-split exchange below: same row, same 8-group
         const float v0 = (acc[i][j][0] + b4[j].x + r4[j].x) * p.out_scale;
         const float v1 = (acc[i][j][1] + b4[j].y + r4[j].y) * p.out_scale;
         const float v2 = (acc[i][j][2] + b4[j].z + r4[j].z) * p.out_scale;
         const float v3 = (acc[i][j][3] + b4[j].w + r4[j].w) * p.out_scale;
-        if (o32) *(float4*)(o32 + (int64_t)orow[i] * p.ldo32 + nbj[j]) = make_float4(v0, v1, v2, v3);
+        if (o32 && live) *(float4*)(o32 + (int64_t)orow[i] * p.ldo32 + nbj[j]) = make_float4(v0, v1, v2, v3);
         if (oact) {
           float a0, a1, a2, a3;
-          if (VEC_ONLY && p.act == CV_ACT_SNAKE) {   // the HiFT convs: no 7-way switch per element in a 64-element unrolled epilogue
+          if (p.act == CV_ACT_NONE) {                // the two common cases first: apply_act's 7-way switch per element measured 35 - 60 us per conv
+            a0 = v0; a1 = v1; a2 = v2; a3 = v3;      // launch at 8 x 60 000 x 64 (tools/hift_conv_bench.py) in a 64-element unrolled epilogue
+          } else if (p.act == CV_ACT_SNAKE) {
             a0 = act_snake(v0, ap4[j].x); a1 = act_snake(v1, ap4[j].y); a2 = act_snake(v2, ap4[j].z); a3 = act_snake(v3, ap4[j].w);
           } else {
             a0 = apply_act(p.act, v0, ap4[j].x, p.act_slope); a1 = apply_act(p.act, v1, ap4[j].y, p.act_slope);
             a2 = apply_act(p.act, v2, ap4[j].z, p.act_slope); a3 = apply_act(p.act, v3, ap4[j].w, p.act_slope);
           }
-          if (DT == CV_F32 && (p.x3_flags & 4)) store_split4(oact, (int64_t)orow[i] * p.ldoa + nbj[j], a0, a1, a2, a3);
-          else store_act4<DT>(oact, (int64_t)orow[i] * p.ldoa + nbj[j], a0, a1, a2, a3);
+          if (DT == CV_F32 && (p.x3_flags & 4)) {
+            // pre-split output: the lanes lg and lg ^ 1 of a row hold the two halves of one 8-value group.  One v_permlane16_swap per register
+            // hands the even lane both hi halves and the odd lane both lo halves: each lane writes ONE 16-byte chunk ([8 x hi] or [8 x lo]) instead
+            // of two 8-byte pieces of both (cdna guide T21: an epilogue of narrow stores is store-issue bound).  Executed by every lane.
+            uint2 hi, lo;
+            split_pack4(a0, a1, a2, a3, hi, lo);
+            const auto s0 = __builtin_amdgcn_permlane16_swap(hi.x, lo.x, false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(hi.y, lo.y, false, false);
+            if (live) {
+              const int64_t idx = (int64_t)orow[i] * p.ldoa + nbj[j];
+              *(uint4*)(oact + (idx & ~(int64_t)7) * 4 + ((idx >> 2) & 1) * 16) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            }
+          } else if (live) {
+            store_act4<DT>(oact, (int64_t)orow[i] * p.ldoa + nbj[j], a0, a1, a2, a3);
+          }
         }
       }
     }
@@ -213,7 +227,7 @@ __device__ __forceinline__ void gemm_epilogue(const cv_gemm_params& p, f32x4_t (
 // The split happens when a tile is written to LDS: the 128-byte row that held 32 floats holds 32 hi (chunks 0-3) + 32 lo
 // (chunks 4-7) bf16 values, i.e. exactly the two fragment reads of the 16-bit path, and 3 MFMA 16x16x32 replace the
 // 8 exact-f32 16x16x4 per K tile (the f32 MFMA peak is 1/16 of bf16: the HiFT / BigVGAN convs were MFMA-bound on it).
-// PS (with X3): both operands arrive PRE-SPLIT (store_split4's 8-value group format: activations written so by the producing launch's
+// PS (with X3): both operands arrive PRE-SPLIT (the 8-value group format above: activations written so by the producing launch's
 // epilogue, weights converted once on the host) — the LDS store is then one 16-byte copy per chunk, conflict-free like the 16-bit path
 // (the split form's 8-byte hi / lo stores showed 33 % LDS bank-conflict cycles, profiles/r01_k).  Without it the split costs ~150 VALU
 // instructions per thread per K tile against 24 MFMAs per wave (the HiFT convs re-split every activation once per tap and tile column).
@@ -718,11 +732,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_win_kernel(const cv_gemm
   gemm_epilogue<CV_F32, MT, NT, true>(p, acc, m0, n0, wave_m, wave_n, lane, z, z0, z1);
 }
 
-// CV_CONV_WIN=1 opts the qualifying convs in (default: gemm_kernel); CV_CONV_WIN_SHAPE=WMxWN forces one workgroup shape.  Both are read
-// per call.  Measured (tools/hift_conv_bench.py, profiles/r03_hift_conv_bench.log): per tap the window kernel's MFMA loop is
-// faster (11.4 vs 14.4 us per tap at 8 x 60 000 x 64, 17 % at 8 x 20 000 x 128 k = 11) but its window load and epilogue are not overlapped with
-// compute (131 vs 65 us of fixed time per conv at 8 x 60 000 x 64: the conv's activation traffic alone is 49 us at 5 TB/s), so it wins only
-// for C >= 128 with k >= 7 on large grids and loses everywhere else — not the default.
+// CV_CONV_WIN=1 opts the qualifying convs in (default: gemm_kernel); CV_CONV_WIN_SHAPE=WMxWN forces one workgroup shape.  Both are read per
+// call.  Measured (tools/hift_conv_bench.py, profiles/r03_hift_conv_bench.log, DESIGN.md status item 4): alone, on the c1-type launch (snake +
+// pre-split output), the window kernel is 5 - 20 % faster on every batch-8 shape (1 282 vs 1 501 us over the nine shapes) and within +-10 % on
+// single-utterance grids; inside a decode, where every second conv also reads the residual and writes the fp32 stream, the advantage shrinks to 3 %
+// at batch 8 (12.3 vs 12.65 ms of conv time) and turns into a 4 % loss at batch 1 (3.67 vs 3.51 ms per decode) — its window load, taps and
+// epilogue are serial inside a workgroup at 2 - 3 workgroups per CU.  Not the default.
 constexpr int CONV_WIN_LDS_MAX = 80 * 1024;   // two workgroups per CU
 
 template <int WM, int WN>
@@ -751,11 +766,12 @@ int dispatch_conv_win(const cv_gemm_params& p, hipStream_t st) {
   int wm, wn = (p.N >= 128) ? 2 : 1;
   if (force_wm) { wm = force_wm == 3 ? 2 : force_wm; wn = min(force_wn, wn); }
   else {
-    // four waves per workgroup (128 x 128 or 256 x 64) when that still gives every CU a workgroup; else halve the rows, then the columns
-    wm = 4 / wn;
-    auto wgs = [&](int a, int b) { return (long long)((p.M + 64 * a - 1) / (64 * a)) * ((p.N + 64 * b - 1) / (64 * b)) * p.batch; };
-    while (wm > 1 && wgs(wm, wn) < 256) wm >>= 1;
-    if (wn > 1 && wgs(wm, wn) < 256) wn = 1;
+    // waves per workgroup by the number of 64 x 64 wave tiles in the launch (tools/hift_conv_bench.py: one-wave workgroups win on single-utterance
+    // grids of 250 - 940 tiles, two waves at 2 000, four from 5 000); four waves = 128 x 128 where N allows, else 256 x 64
+    const long long tiles = (long long)((p.M + 63) / 64) * ((p.N + 63) / 64) * p.batch;
+    const int nw = tiles >= 4096 ? 4 : (tiles >= 1536 ? 2 : 1);
+    if (nw < 2) wn = 1;
+    wm = nw / wn;
   }
   while (wm > 1 && (size_t)((64 * wm + halo + 3) & ~3) * 256 > (size_t)CONV_WIN_LDS_MAX) wm >>= 1;
   if ((size_t)((64 * wm + halo + 3) & ~3) * 256 > (size_t)CONV_WIN_LDS_MAX) return CONV_WIN_NO;

@@ -106,7 +106,9 @@ def test_stage_abi_decode_equals_python_composed_decode(tag, dt, mode):
 @pytest.mark.parametrize("tag", ["tiny", "v2"])
 def test_presplit_storage_is_bit_identical(tag, monkeypatch):
     """bf16x3 decoder convs with PRE-SPLIT activation / weight storage (hi / lo bf16 planes per 4 values, written once by the producing
-    epilogue) against the plain bf16x3 launches that split every operand tile as it is staged: same hi / lo bits, same MFMAs."""
+    epilogue) against the plain bf16x3 launches that split every operand tile as it is staged: same hi / lo bits, same MFMAs — bit-identical
+    on the implicit-GEMM kernel (the default).  The opt-in activation-window kernel (CV_CONV_WIN=1) sums chunk-major (64 channels at a time,
+    then taps) instead of tap-major: same products, fp32 re-association only."""
     from cosyvoice_amd.hift import HiFTGenerator
     cfg = CFGS[tag]
     sd = hift_state_dict(cfg)
@@ -115,10 +117,12 @@ def test_presplit_storage_is_bit_identical(tag, monkeypatch):
     mel = torch.clamp(torch.randn(B, 80, T) * 2 - 6, -11.5, 2.0).cuda()
     s = (torch.randn(B, 1, T * cfg.total_upsample) * 0.05).cuda()
     outs = {}
-    for flag in ("1", "0"):
+    for flag, win in (("1", "0"), ("0", "0"), ("1", "1")):
         monkeypatch.setenv("CV_HIFT_PRESPLIT", flag)
+        monkeypatch.setenv("CV_CONV_WIN", win)
         m = HiFTGenerator(cfg, dtype=torch.float32, f32_products="bf16x3").load_state_dict(sd)
         assert m.presplit == (flag == "1")
-        outs[flag] = m.decode(mel, s).clone()
+        outs[flag + win] = m.decode(mel, s).clone()
     torch.cuda.synchronize()
-    assert outs["1"].abs().max().item() > 0 and torch.equal(outs["1"], outs["0"])
+    assert outs["10"].abs().max().item() > 0 and torch.equal(outs["10"], outs["00"])
+    assert (outs["11"] - outs["10"]).abs().max().item() < 2e-6
