@@ -1,5 +1,5 @@
 """Times the HiFT v2 ResBlock conv launches (stride-1 bf16x3 convs on pre-split operands) one shape at a time: gemm_kernel (implicit
-im2col, the default) against conv_win_kernel (CV_CONV_WIN=1) in every workgroup shape, each as a 10-launch hipGraph.   python tools/hift_conv_bench.py [B ...]"""
+im2col, the default) against conv_win_kernel (CV_CONV_WIN=1) in every workgroup shape, each as a 10-launch hipGraph.  BENCH_C2=1: the second conv of a ResBlock unit (fp32 residual in, fp32 stream out as well).   python tools/hift_conv_bench.py [B ...]"""
 import os
 import sys
 
@@ -23,6 +23,9 @@ def main():
                 bias = torch.randn(C, device=dev)
                 alpha = torch.rand(C, device=dev) + 0.5
                 oa = torch.empty(B, T, C, device=dev)
+                c2 = os.environ.get("BENCH_C2", "0") == "1"      # the ResBlock's second conv: + fp32 residual in, + fp32 stream out
+                res = torch.randn(B, T, C, device=dev) if c2 else None
+                o32 = torch.empty(B, T, C, device=dev) if c2 else None
                 flops = 2.0 * B * T * C * C * k * 3
                 row = []
                 for tag, env in (("gemm", {"CV_CONV_WIN": "0"}), ("auto", {"CV_CONV_WIN": "1"}), ("4x1", {"CV_CONV_WIN": "1", "CV_CONV_WIN_SHAPE": "4x1"}), ("2x2", {"CV_CONV_WIN": "1", "CV_CONV_WIN_SHAPE": "2x2"}),
@@ -36,7 +39,7 @@ def main():
 
                     def run():
                         ops.conv1d_cl(x, W, k, dilation=dil, pad_left=(k * dil - dil) // 2, bias=bias, act=ops.ACT_SNAKE, act_param=alpha, out_act=oa,
-                                      dtype=L.CV_F32X3, x3_flags=7)
+                                      res=res, out_f32=o32, dtype=L.CV_F32X3, x3_flags=7)
                     run()
                     torch.cuda.synchronize()
                     reps = 10
