@@ -30,6 +30,8 @@ import statistics
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between the ranks of one node needs it on this driver
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
