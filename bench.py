@@ -181,6 +181,9 @@ def main():
                     help="torch.distributed backend; gloo only to rehearse the multi-process path with several ranks on ONE GPU")
     ap.add_argument("--llm-merge", type=int, default=4,
                     help="consecutive 8-utterance batches decoded by one token loop (4: 32 rows = two 16-row MFMA groups share every weight stream)")
+    ap.add_argument("--flow-merge", type=int, default=3,
+                    help="consecutive batches of one decode job that share one flow + HiFT pass (24 utterances fill the flow's 192 CUs in whole "
+                         "rounds of workgroups: 11.5 vs 13.9 ms per utterance at 8, tools/flow_share_probe.py)")
     ap.add_argument("--llm-loops", type=int, default=2,
                     help="concurrent decode loops (one utterance batch each, own KV caches) on the decode CUs")
     args = ap.parse_args()
@@ -222,6 +225,9 @@ def main():
     hift = HiFTGenerator(hc, dtype=torch.float32)
     model = CosyVoice2Model(llm, flow, hift, fp16=False).load_state_dicts(lsd, fsd, hsd)
     model.llm_merge = max(1, args.llm_merge)
+    model.flow_merge = max(1, args.flow_merge)
+    if model.flow_merge >= 3:
+        model.llm_ramp = (2, 2, 3)   # merged flow passes want their first groups sooner and larger (profiles/r03_flow_merge_sweeps.log)
     # the fork drives CosyVoice2 modules through CosyVoiceModel wiring (full attention, model.py:50); the benchmark keeps
     # CosyVoice2Model's own chunk-50 encoder mask (model.py:314)
     flow.decoder.use_graph = True
@@ -290,6 +296,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up (untimed, like loading the weights): every graph capture / workspace allocation of the shapes the pipeline can meet — decode
+    # contexts at 8 .. 8 x llm_merge rows, flow + HiFT groups of 1 .. flow_merge batches on the flow CUs and on all CUs
+    wb = make_batch(local=(rank == 0))   # shapes only: the other ranks' slot holds zeros, nothing is broadcast
+    model.warm_pipeline_shapes(wb, N_GEN, llm_cu_slots=args.llm_cu_slots, llm_loops=args.llm_loops)
+    wb["on_done"]()
     if args.warmup > 0:
         w = run_steps(args.warmup)
         log(f"[rank {rank}] warmup: wav {tuple(w.shape)} absmax {w.abs().max().item():.3f}")
@@ -352,7 +363,7 @@ def main():
             "config": {"workload": "C4 full LLM->flow->HiFT pipeline, 8 utterances x 10 s per GPU, 10 s prompt "
                                    "(prefill 282, N_g 250, flow T 1000 x 10 CFG Euler steps, HiFT 500 frames); token loop: " + replay,
                        "utterances_per_gpu": B, "rtf": round(elapsed / audio_s, 6), "parallelism": f"utterance-parallel x{world}",
-                       "llm_cu_slots_per_xcd": args.llm_cu_slots, "llm_decode_loops": args.llm_loops, "batches_per_decode_loop": args.llm_merge,
+                       "llm_cu_slots_per_xcd": args.llm_cu_slots, "llm_decode_loops": args.llm_loops, "batches_per_decode_loop": args.llm_merge, "batches_per_flow_pass": args.flow_merge,
                        "flow_fused_tblock": bool(flow.decoder.estimator.fused), "batch1": b1, "dist": dist_info},
         }
         out.update(extras)

@@ -58,6 +58,8 @@ class CosyVoice2Model:
         self.llm_cu_slots = 8   # tts_batches: CU slots per XCD (of 32) owned by the decode loops; 0 = no partition
         self.llm_loops = 2      # tts_batches: concurrent decode loops (each its own batch / KV caches) on those CUs
         self.llm_merge = 1      # tts_batches: consecutive batches decoded by ONE token loop (rows <= llm.max_batch)
+        self.flow_merge = 1     # tts_batches: consecutive batches of one decode job that share ONE flow + HiFT pass
+        self.llm_ramp = (1, 2, 2, 3)   # tts_batches: batches per decode job while the pipeline fills (then llm_merge); CV_LLM_RAMP overrides
         self.lock = threading.Lock()
         # The reference's modules are re-entrant (every call builds its own activations / KV cache) and it interleaves requests:
         # one LLM thread + side stream per tts() call (cli/model.py:62,119,189).  Here a decode loop owns KV caches, device state and
@@ -336,6 +338,47 @@ class CosyVoice2Model:
         self._llm_contexts = ctxs
         return ctxs[:n]
 
+    @torch.no_grad()
+    def warm_pipeline_shapes(self, b, n_tokens: int, llm_cu_slots: Optional[int] = None, llm_loops: Optional[int] = None):
+        """Set-up, not work: run every shape the partitioned pipeline of ``tts_batches`` can meet once — each decode context at 1 ..
+        ``llm_merge`` batches of rows (prefill workspace + the captured step graph of that row count), flow + HiFT at 1 .. ``flow_merge``
+        batches on the flow CUs and on all CUs (the drain) — so that no graph capture or workspace allocation lands inside a run.
+        ``b``: one batch dict as given to ``tts_batches`` (its ``forced`` lists, if any, are used for the two decode steps)."""
+        k = self.llm_cu_slots if llm_cu_slots is None else llm_cu_slots
+        n_llm = max(1, self.llm_loops if llm_loops is None else llm_loops)
+        if not k:
+            return
+        llm_parts, flow_part, _, prefill_parts, hift_part = self.cu_partition(k, n_llm)
+        B = len(b["texts"])
+        forced = b.get("forced")
+        for ctx, st, pf in zip(self.llm_contexts(n_llm), llm_parts, prefill_parts):
+            for j in range(1, max(1, int(self.llm_merge)) + 1):
+                if j * B > self.llm.max_batch:
+                    break
+                with torch.cuda.stream(st):
+                    ctx.generate_batch(b["texts"] * j, b["prompt_texts"] * j, b["llm_prompt_speech_tokens"] * j,
+                                       forced=None if forced is None else [list(t) for t in forced] * j, steps_per_poll=64, max_steps=2,
+                                       prefill_stream=pf if self.prefill_on_flow_cus else None)
+        est = getattr(getattr(self.flow, "decoder", None), "estimator", None)
+        flow_full = torch.cuda.Stream(self.device)
+        zero = torch.zeros(1, 1, 0)
+        for budget, stream in (((32 - k) * 8, flow_part), (0, flow_full)):
+            if est is not None:
+                est.cu_budget = budget
+            for j in range(1, max(1, int(self.flow_merge)) + 1):
+                rep = lambda t: torch.cat([t] * j, dim=0)
+                tok = torch.randint(0, self.flow.cfg.vocab_size, (j * B, n_tokens), dtype=torch.int32).to(self.device)
+                with torch.cuda.stream(stream):
+                    mel = self.flow.inference_batch(tok, rep(b["flow_prompt_speech_tokens"]), rep(b["prompt_speech_feats"]),
+                                                    rep(b["flow_embeddings"])).contiguous().clone()
+                stream.synchronize()
+                with torch.cuda.stream(hift_part):
+                    self.hift.inference(speech_feat=mel, cache_source=zero)
+                hift_part.synchronize()
+        if est is not None:
+            est.cu_budget = 0
+        torch.cuda.synchronize()
+
     def tts_batches(self, batches, to_host: bool = True, llm_cu_slots: Optional[int] = None, llm_loops: Optional[int] = None):
         """Generator over a list of utterance batches (each a dict of tts_batch's arguments), software-pipelined the way
         the reference overlaps its LLM thread with flow/HiFT (cli/model.py:62,119,189): the LLM decode of later batches
@@ -424,26 +467,53 @@ class CosyVoice2Model:
                 with llm_state_lock:
                     llm_state["running"] -= 1
 
-        def hift_job(mel, mel_ready, t_job):
-            """HiFT (+ D2H) of one equal-length batch on its own stream over the flow CUs: the vocoder of batch i fills the CUs the
-            flow of batch i + 1 leaves idle (the tail round of every attention launch, tile quantisation of the row-block
+        def split_rows(wav, counts, done):
+            """result of a flow group -> one (wav, done) per batch of the group (rows in batch order)"""
+            if isinstance(wav, list):   # ragged: per-utterance waveforms
+                out, o = [], 0
+                for c in counts:
+                    out.append((wav[o:o + c], done))
+                    o += c
+                return out
+            return [(w, done) for w in torch.split(wav, counts, dim=0)] if len(counts) > 1 else [(wav, done)]
+
+        def hift_job(mel, mel_ready, t_job, counts):
+            """HiFT (+ D2H) of one equal-length flow group on its own stream over the flow CUs: the vocoder of group i fills the CUs the
+            flow of group i + 1 leaves idle (the tail round of every attention launch, tile quantisation of the row-block
             kernels) instead of extending the flow stream's critical path (17 of a 91 ms job on all CUs)."""
             with torch.no_grad(), torch.cuda.stream(hift_part):
                 hift_part.wait_event(mel_ready)
                 mel.record_stream(hift_part)
                 wav, _ = self.hift.inference(speech_feat=mel, cache_source=torch.zeros(1, 1, 0))
                 if to_host:
-                    res = wav.cpu(), None
+                    res = split_rows(wav.cpu(), counts, None)
                     if self.pipeline_stats is not None:
-                        self.pipeline_stats.append(("flow", 1, t_job, time.perf_counter()))
+                        self.pipeline_stats.append(("flow", len(counts), t_job, time.perf_counter()))
                     return res
                 wav = wav.clone()
                 done = torch.cuda.Event()
                 done.record(hift_part)
-                return wav, done
+                return split_rows(wav, counts, done)
 
-        def flow_job(b, llm_fut, idx, ready, stream):
-            toks = llm_fut.result()[idx]
+        def flow_job(grp, llm_fut, idxs, ready, stream):
+            """Flow + HiFT of ``grp`` = consecutive batches of ONE decode job (``flow_merge`` of them at most) as a single pass: the row-block
+            kernels run in whole rounds of workgroups over the stream's CUs, so 16 or 24 utterances cost less per utterance than 8
+            (tools/flow_share_probe.py: 13.9 / 12.3 / 11.5 ms per utterance at 8 / 16 / 24 on the 192-CU share).  -> one (wav, done) per batch."""
+            all_toks = llm_fut.result()
+            counts = [len(all_toks[i]) for i in idxs]
+            toks = [t for i in idxs for t in all_toks[i]]
+            if len(grp) == 1:
+                b = grp[0]
+            else:
+                keys = ("flow_prompt_speech_tokens", "prompt_speech_feats", "flow_embeddings")
+                if any(b[k_].shape[1:] != grp[0][k_].shape[1:] for b in grp for k_ in keys):
+                    # prompts of different lengths: no common batch layout -> the batches one after the other, as without merging
+                    out = []
+                    for b, i in zip(grp, idxs):
+                        r = flow_job([b], llm_fut, [i], ready, stream)
+                        out.extend(r.result() if hasattr(r, "result") else r)
+                    return out
+                b = {k_: torch.cat([bb[k_] for bb in grp], dim=0) for k_ in keys}
             t_job = time.perf_counter()
             with llm_state_lock:
                 # every decode job of the run has ended and none is left to submit: the decode CUs are idle for good, so the remaining
@@ -456,37 +526,45 @@ class CosyVoice2Model:
             if self.overlap_hift and all(len(t) == n_t for t in toks):
                 with torch.no_grad(), torch.cuda.stream(stream):
                     stream.wait_event(ready)
-                    stream.wait_stream(flow_part if stream is flow_full else flow_full)  # workspaces of the previous batch
+                    stream.wait_stream(flow_part if stream is flow_full else flow_full)  # workspaces of the previous group
                     tok = torch.tensor(toks, dtype=torch.int32, device=self.device)
                     mel = self.flow.inference_batch(tok, b["flow_prompt_speech_tokens"], b["prompt_speech_feats"], b["flow_embeddings"])
-                    mel = mel.contiguous().clone()   # the flow's output buffer is rewritten by the next batch
+                    mel = mel.contiguous().clone()   # the flow's output buffer is rewritten by the next group
                     mel_ready = torch.cuda.Event()
                     mel_ready.record(stream)
-                return hift_pool.submit(hift_job, mel, mel_ready, t_job)   # one worker: vocoder workspaces are used in batch order
+                return hift_pool.submit(hift_job, mel, mel_ready, t_job, counts)   # one worker: vocoder workspaces are used in group order
             with torch.no_grad(), torch.cuda.stream(stream):
                 stream.wait_event(ready)
-                stream.wait_stream(flow_part if stream is flow_full else flow_full)  # workspaces of the previous batch
+                stream.wait_stream(flow_part if stream is flow_full else flow_full)  # workspaces of the previous group
                 if self.overlap_hift:
-                    hift_pool.submit(lambda: None).result()   # earlier batches' vocoder jobs are enqueued ...
+                    hift_pool.submit(lambda: None).result()   # earlier groups' vocoder jobs are enqueued ...
                     stream.wait_stream(hift_part)             # ... and done with the vocoder workspaces before this one uses them
                 wav = self._flow_hift(b, toks)
                 if to_host:
-                    res = ([w.cpu() for w in wav] if isinstance(wav, list) else wav.cpu()), None
+                    res = split_rows([w.cpu() for w in wav] if isinstance(wav, list) else wav.cpu(), counts, None)
                     if self.pipeline_stats is not None:
-                        self.pipeline_stats.append(("flow", 1, t_job, time.perf_counter()))
+                        self.pipeline_stats.append(("flow", len(grp), t_job, time.perf_counter()))
                     return res
                 # the equal-length path returns a view of HiFT's per-shape workspace, which the next flow_job overwrites on this
                 # stream as soon as its tokens arrive: hand the consumer its own copy (made here, ordered before `done`)
                 wav = [w.clone() for w in wav] if isinstance(wav, list) else wav.clone()
                 done = torch.cuda.Event()
                 done.record(stream)
-                return wav, done
+                return split_rows(wav, counts, done)
+
+        class _Pick:
+            """the result of batch ``j`` of a flow group's future"""
+            def __init__(self, fut, j):
+                self.fut, self.j = fut, j
+
+            def result(self):
+                r = self.fut.result()
+                if hasattr(r, "result"):   # the equal-length path hands back its vocoder job
+                    r = r.result()
+                return r[self.j]
 
         def collect(fut):
-            r = fut.result()
-            if hasattr(r, "result"):   # the equal-length path hands back its vocoder job
-                r = r.result()
-            wav, done = r
+            wav, done = fut.result()
             if done is not None:
                 caller.wait_event(done)
             return wav
@@ -496,11 +574,12 @@ class CosyVoice2Model:
         inflight = deque()
         first = True
         merge = max(1, int(getattr(self, "llm_merge", 1)))
+        fmerge = max(1, int(getattr(self, "flow_merge", 1)))
         llm_state_lock = threading.Lock()
         llm_state = {"running": 0, "all_submitted": False}
         # pipeline fill: the first decode jobs are small so that the flow stream gets its first batches early and is then fed without a
         # gap while the job size grows to `merge` (1, 2, 2, 3, merge, ...: with 4 batches per job from the start the flow CUs idled ~0.2 s)
-        ramp = [int(v) for v in os.environ.get("CV_LLM_RAMP", "1,2,2,3").split(",") if v]
+        ramp = [int(v) for v in os.environ.get("CV_LLM_RAMP", ",".join(str(v) for v in self.llm_ramp)).split(",") if v]
         n_jobs = 0
         with ThreadPoolExecutor(max_workers=n_llm) as llm_pool, ThreadPoolExecutor(max_workers=1) as flow_pool, \
                 ThreadPoolExecutor(max_workers=1) as hift_pool:
@@ -524,9 +603,12 @@ class CosyVoice2Model:
                         llm_state["running"] += 1
                         llm_state["all_submitted"] = nxt is None
                     lf = llm_pool.submit(llm_job, bs, ready, first)
-                    for i, b in enumerate(bs):
-                        last = nxt is None and i == len(bs) - 1
-                        inflight.append((b, flow_pool.submit(flow_job, b, lf, i, ready, flow_full if last else flow_part)))
+                    for g0 in range(0, len(bs), fmerge):   # flow groups: up to `flow_merge` consecutive batches of this decode job per pass
+                        idxs = list(range(g0, min(g0 + fmerge, len(bs))))
+                        last = nxt is None and idxs[-1] == len(bs) - 1
+                        gf = flow_pool.submit(flow_job, [bs[i] for i in idxs], lf, idxs, ready, flow_full if last else flow_part)
+                        for j, i in enumerate(idxs):
+                            inflight.append((bs[i], _Pick(gf, j)))
                     first = False
                 b_done, fut = inflight.popleft()
                 try:

@@ -8,13 +8,13 @@ from cosyvoice_amd.weights import flow_state_dict, hift_state_dict, llm_state_di
 pytestmark = pytest.mark.gpu
 
 
-def _model():
+def _model(max_batch=4):
     from cosyvoice_amd.flow import CausalMaskedDiffWithXvec
     from cosyvoice_amd.hift import HiFTGenerator
     from cosyvoice_amd.llm import Qwen2LM
     from cosyvoice_amd.model import CosyVoice2Model
     lc, fc, hc = LlmConfig.tiny(), FlowConfig.tiny(), HiftConfig.tiny()
-    llm = Qwen2LM(lc, dtype=torch.bfloat16, max_batch=4, ctx_max=256, max_out=256)
+    llm = Qwen2LM(lc, dtype=torch.bfloat16, max_batch=max_batch, ctx_max=256, max_out=256)
     flow = CausalMaskedDiffWithXvec(fc, dtype=torch.float16)
     hift = HiFTGenerator(hc, dtype=torch.float32)
     m = CosyVoice2Model(llm, flow, hift, fp16=False).load_state_dicts(llm_state_dict(lc), flow_state_dict(fc), hift_state_dict(hc))
@@ -393,4 +393,55 @@ def test_tts_batches_conditioning_slots_lifecycle(cu_slots):
         solo = m.tts_batch(texts, [pt] * B, [ps] * B, ps.expand(B, -1), pf.expand(B, -1, -1), em.expand(B, -1), forced=forced)
         assert solo.shape == wavs[i].shape
         assert (solo.abs().mean() - wavs[i].abs().mean()).abs().item() < 0.02 * max(1e-3, solo.abs().mean().item()) + 5e-3
+    m.close()
+
+
+@pytest.mark.parametrize("fm", [2, 3])
+def test_tts_batches_flow_merge_matches_unmerged(fm):
+    """``flow_merge``: consecutive batches of one decode job share ONE flow + HiFT pass (the row-block kernels fill the flow CUs in whole
+    rounds of workgroups, so 16 / 24 utterances cost less per utterance than 8).  Every utterance's mel must be bit-identical to the
+    unmerged run (the flow is batch-invariant), each batch must get ITS rows back in order, and on_done must follow the batch's result."""
+    import hashlib
+    m, lc, fc, hc = _model(max_batch=8)      # 3 batches of 2 rows per decode job
+    n_batches, B, n_p = 9, 2, 10
+    g = torch.Generator().manual_seed(33)
+    texts = [torch.randint(0, lc.vocab_size, (1, 6), generator=g, dtype=torch.int32).cuda() for _ in range(B)]
+    conds, forced = [], []
+    for i in range(n_batches):
+        pf = torch.clamp(torch.randn(1, 2 * n_p, 80, generator=g) * 2 - 6, -11.5, 2.0).cuda()
+        em = torch.randn(1, fc.spk_embed_dim, generator=g).cuda()
+        ps = torch.randint(0, lc.speech_token_size, (1, n_p), generator=g, dtype=torch.int32).cuda()
+        pt = torch.randint(0, lc.vocab_size, (1, 4), generator=g, dtype=torch.int32).cuda()
+        conds.append((pf, em, ps, pt))
+        forced.append([torch.randint(0, lc.speech_token_size, (12,), generator=g).tolist() for _ in range(B)])   # own tokens per batch
+
+    def run(merge):
+        m.llm_merge, m.flow_merge = 3, merge
+        digests, done = [], []
+        orig = m.flow.inference_batch
+
+        def rec(tok, *a, **k):
+            mel = orig(tok, *a, **k)
+            for j in range(mel.shape[0]):
+                digests.append((tuple(tok[j].tolist()), hashlib.sha256(mel[j].float().cpu().numpy().tobytes()).hexdigest()))
+            return mel
+        m.flow.inference_batch = rec
+        try:
+            def batches():
+                for i, (pf, em, ps, pt) in enumerate(conds):
+                    yield dict(texts=texts, prompt_texts=[pt] * B, llm_prompt_speech_tokens=[ps] * B, flow_prompt_speech_tokens=ps.expand(B, -1),
+                               prompt_speech_feats=pf.expand(B, -1, -1), flow_embeddings=em.expand(B, -1), forced=forced[i],
+                               on_done=lambda i=i: done.append(i))
+            wavs = [w.clone() for w in m.tts_batches(batches(), to_host=True, llm_cu_slots=8, llm_loops=2)]
+        finally:
+            m.flow.inference_batch = orig
+        return wavs, dict(digests), done, [len(d) for d in [digests]]
+    w1, d1, done1, _ = run(1)
+    wm, dm, donem, _ = run(fm)
+    assert done1 == list(range(n_batches)) and donem == list(range(n_batches))
+    assert len(d1) == n_batches * B and d1 == dm            # keyed by the utterance's own token list: same mel bits, merged or not
+    assert len(wm) == n_batches
+    for a, b in zip(w1, wm):
+        assert a.shape == b.shape and torch.isfinite(b).all()
+        assert (a.abs().mean() - b.abs().mean()).abs().item() < 0.02 * max(1e-3, a.abs().mean().item()) + 5e-3   # vocoder noise differs
     m.close()

@@ -67,6 +67,7 @@ def main():
     hift = HiFTGenerator(hc, dtype=torch.float32)
     model = CosyVoice2Model(llm, flow, hift, fp16=False).load_state_dicts(llm_state_dict(lc), flow_state_dict(fc), hift_state_dict(hc))
     model.llm_merge = 2
+    model.flow_merge = int(os.environ.get("REHEARSAL_FLOW_MERGE", "2"))   # flow groups of two batches: the merged pass the bench runs
     flow.decoder.use_graph = True
     dev = torch.device("cuda")
     n_global = B.UTT_PER_GPU * W
@@ -86,9 +87,12 @@ def main():
 
     def recording(*a, **k):
         mel = orig(*a, **k)
-        step, ids = order.pop(0)
-        for j, u in enumerate(ids):
-            digests[f"{step}:{u}"] = hashlib.sha256(mel[j].float().cpu().numpy().tobytes()).hexdigest()
+        row = 0
+        while row < mel.shape[0]:     # a merged flow pass (flow_merge) covers several consecutive batches, rows in batch order
+            step, ids = order.pop(0)
+            for u in ids:
+                digests[f"{step}:{u}"] = hashlib.sha256(mel[row].float().cpu().numpy().tobytes()).hexdigest()
+                row += 1
         return mel
     flow.inference_batch = recording
 
