@@ -386,7 +386,9 @@ class CosyVoice2Model:
         (callable, e.g. the RCCL conditioning broadcast; called from the calling thread, in batch order) and ``on_done`` (callable,
         called from the calling thread once the batch's result has been collected, i.e. when no job reads its inputs any more:
         where a pipelined caller recycles the batch's conditioning buffer, cosyvoice_amd.dist.ConditioningRing).  ``batches`` may be
-        a generator: a batch is taken from it (and may acquire its buffers) only when the pipeline admits it.
+        a generator: a batch is taken from it (and may acquire its buffers) only when the pipeline admits it.  On the partitioned path the generator and
+        ``on_start`` run with a private non-blocking stream current (ordered behind everything the caller enqueued before the call): GPU work they issue
+        through torch is ordered before the batch's jobs without touching the caller's stream.
 
         ``llm_cu_slots`` (default ``self.llm_cu_slots``) > 0 partitions the GPU: the decode loops run on that many CUs
         of every XCD and flow + HiFT on the others, each from its own host thread, every captured graph replayed launch by
@@ -434,6 +436,12 @@ class CosyVoice2Model:
             est.cu_budget = (32 - k) * 8   # the flow's launches run on that many CUs: its row-block kernels size their tiles for it
         flow_full = torch.cuda.Stream(self.device)   # all CUs: the last batch's flow + HiFT run after every decode loop ended
         caller = torch.cuda.current_stream()
+        # Admission work (drawing a batch from ``batches``, its on_start, the `ready` event) runs on a private non-blocking stream, not on the
+        # caller's: when that is the legacy default stream every operation on it — a conditioning copy, an event record — is an implicit barrier
+        # against all the CU-masked streams of the pipeline (they are blocking streams), i.e. the whole pipeline drained once per admitted
+        # batch (625 -> 638 audio-s/s at 20 passes, 639 -> 664 at 32, profiles/r03_flow_merge_sweeps.log).
+        adm = torch.cuda.Stream(self.device)
+        adm.wait_stream(caller)   # whatever the caller enqueued before the call is visible to the first batch
         ctxs = queue.Queue()
         for c, st, pf in zip(self.llm_contexts(n_llm), llm_parts, prefill_parts):
             ctxs.put((c, st, pf))
@@ -570,7 +578,11 @@ class CosyVoice2Model:
             return wav
 
         it = iter(batches)
-        nxt = next(it, None)
+
+        def draw():
+            with torch.cuda.stream(adm):
+                return next(it, None)
+        nxt = draw()
         inflight = deque()
         first = True
         merge = max(1, int(getattr(self, "llm_merge", 1)))
@@ -592,12 +604,13 @@ class CosyVoice2Model:
                     while nxt is not None and len(bs) < job_batches and rows + len(nxt["texts"]) <= self.llm.max_batch:
                         rows += len(nxt["texts"])
                         bs.append(nxt)
-                        nxt = next(it, None)
-                    for b in bs:
-                        if b.get("on_start") is not None:
-                            b["on_start"]()   # e.g. the conditioning broadcast: same order on every rank, never from worker threads
+                        nxt = draw()
                     ready = torch.cuda.Event()
-                    ready.record(caller)
+                    with torch.cuda.stream(adm):
+                        for b in bs:
+                            if b.get("on_start") is not None:
+                                b["on_start"]()   # e.g. the conditioning broadcast: same order on every rank, never from worker threads
+                        ready.record(adm)
                     n_jobs += 1
                     with llm_state_lock:
                         llm_state["running"] += 1
