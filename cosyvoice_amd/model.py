@@ -521,7 +521,8 @@ class CosyVoice2Model:
                         r = flow_job([b], llm_fut, [i], ready, stream)
                         out.extend(r.result() if hasattr(r, "result") else r)
                     return out
-                b = {k_: torch.cat([bb[k_] for bb in grp], dim=0) for k_ in keys}
+                b = None   # concatenated on the job's stream, behind `ready` (below): never on this thread's default stream
+            merged = lambda: {k_: torch.cat([bb[k_] for bb in grp], dim=0) for k_ in keys}
             t_job = time.perf_counter()
             with llm_state_lock:
                 # every decode job of the run has ended and none is left to submit: the decode CUs are idle for good, so the remaining
@@ -535,6 +536,8 @@ class CosyVoice2Model:
                 with torch.no_grad(), torch.cuda.stream(stream):
                     stream.wait_event(ready)
                     stream.wait_stream(flow_part if stream is flow_full else flow_full)  # workspaces of the previous group
+                    if b is None:
+                        b = merged()
                     tok = torch.tensor(toks, dtype=torch.int32, device=self.device)
                     mel = self.flow.inference_batch(tok, b["flow_prompt_speech_tokens"], b["prompt_speech_feats"], b["flow_embeddings"])
                     mel = mel.contiguous().clone()   # the flow's output buffer is rewritten by the next group
@@ -547,6 +550,8 @@ class CosyVoice2Model:
                 if self.overlap_hift:
                     hift_pool.submit(lambda: None).result()   # earlier groups' vocoder jobs are enqueued ...
                     stream.wait_stream(hift_part)             # ... and done with the vocoder workspaces before this one uses them
+                if b is None:
+                    b = merged()
                 wav = self._flow_hift(b, toks)
                 if to_host:
                     res = split_rows([w.cpu() for w in wav] if isinstance(wav, list) else wav.cpu(), counts, None)
