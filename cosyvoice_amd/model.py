@@ -58,7 +58,7 @@ class CosyVoice2Model:
         self.llm_cu_slots = 8   # tts_batches: CU slots per XCD (of 32) owned by the decode loops; 0 = no partition
         self.llm_loops = 2      # tts_batches: concurrent decode loops (each its own batch / KV caches) on those CUs
         self.llm_merge = 1      # tts_batches: consecutive batches decoded by ONE token loop (rows <= llm.max_batch)
-        self.flow_merge = 1     # tts_batches: consecutive batches of one decode job that share ONE flow + HiFT pass
+        self.flow_merge = 1     # tts_batches: up to this many consecutive batches whose tokens are ready share ONE flow + HiFT pass
         self.llm_ramp = (1, 2, 2, 3)   # tts_batches: batches per decode job while the pipeline fills (then llm_merge); CV_LLM_RAMP overrides
         self.lock = threading.Lock()
         # The reference's modules are re-entrant (every call builds its own activations / KV cache) and it interleaves requests:
@@ -503,25 +503,21 @@ class CosyVoice2Model:
                 done.record(hift_part)
                 return split_rows(wav, counts, done)
 
-        def flow_job(grp, llm_fut, idxs, ready, stream):
-            """Flow + HiFT of ``grp`` = consecutive batches of ONE decode job (``flow_merge`` of them at most) as a single pass: the row-block
-            kernels run in whole rounds of workgroups over the stream's CUs, so 16 or 24 utterances cost less per utterance than 8
-            (tools/flow_share_probe.py: 13.9 / 12.3 / 11.5 ms per utterance at 8 / 16 / 24 on the 192-CU share).  -> one (wav, done) per batch."""
-            all_toks = llm_fut.result()
-            counts = [len(all_toks[i]) for i in idxs]
-            toks = [t for i in idxs for t in all_toks[i]]
-            if len(grp) == 1:
-                b = grp[0]
-            else:
-                keys = ("flow_prompt_speech_tokens", "prompt_speech_feats", "flow_embeddings")
-                if any(b[k_].shape[1:] != grp[0][k_].shape[1:] for b in grp for k_ in keys):
-                    # prompts of different lengths: no common batch layout -> the batches one after the other, as without merging
-                    out = []
-                    for b, i in zip(grp, idxs):
-                        r = flow_job([b], llm_fut, [i], ready, stream)
-                        out.extend(r.result() if hasattr(r, "result") else r)
-                    return out
-                b = None   # concatenated on the job's stream, behind `ready` (below): never on this thread's default stream
+        keys = ("flow_prompt_speech_tokens", "prompt_speech_feats", "flow_embeddings")
+
+        def flow_job(grp, srcs, readies, stream):
+            """Flow + HiFT of ``grp`` = consecutive batches whose tokens are ready (``flow_merge`` of them at most, same prompt lengths) as a single
+            pass: the row-block kernels run in whole rounds of workgroups over the stream's CUs, so 16 or 24 utterances cost less per utterance
+            than 8 (tools/flow_share_probe.py: 13.9 / 12.3 / 11.5 ms per utterance at 8 / 16 / 24 on the 192-CU share).  ``srcs``: per batch its
+            decode job's future and its index in that job.  -> one (wav, done) per batch."""
+            per_b = [lf.result()[i] for lf, i in srcs]
+            counts = [len(tb) for tb in per_b]
+            toks = [t for tb in per_b for t in tb]
+            ready_evs = []
+            for r in readies:
+                if all(r is not q for q in ready_evs):
+                    ready_evs.append(r)
+            b = grp[0] if len(grp) == 1 else None   # else concatenated on the job's stream, behind `ready` (below): never on this thread's default stream
             merged = lambda: {k_: torch.cat([bb[k_] for bb in grp], dim=0) for k_ in keys}
             t_job = time.perf_counter()
             with llm_state_lock:
@@ -534,7 +530,8 @@ class CosyVoice2Model:
             n_t = len(toks[0])
             if self.overlap_hift and all(len(t) == n_t for t in toks):
                 with torch.no_grad(), torch.cuda.stream(stream):
-                    stream.wait_event(ready)
+                    for r in ready_evs:
+                        stream.wait_event(r)
                     stream.wait_stream(flow_part if stream is flow_full else flow_full)  # workspaces of the previous group
                     if b is None:
                         b = merged()
@@ -545,7 +542,8 @@ class CosyVoice2Model:
                     mel_ready.record(stream)
                 return hift_pool.submit(hift_job, mel, mel_ready, t_job, counts)   # one worker: vocoder workspaces are used in group order
             with torch.no_grad(), torch.cuda.stream(stream):
-                stream.wait_event(ready)
+                for r in ready_evs:
+                    stream.wait_event(r)
                 stream.wait_stream(flow_part if stream is flow_full else flow_full)  # workspaces of the previous group
                 if self.overlap_hift:
                     hift_pool.submit(lambda: None).result()   # earlier groups' vocoder jobs are enqueued ...
@@ -565,16 +563,52 @@ class CosyVoice2Model:
                 done.record(stream)
                 return split_rows(wav, counts, done)
 
-        class _Pick:
-            """the result of batch ``j`` of a flow group's future"""
-            def __init__(self, fut, j):
-                self.fut, self.j = fut, j
+        from concurrent.futures import Future
+        flow_q, flow_cv, flow_state = deque(), threading.Condition(), {"closed": False, "abort": False}
 
-            def result(self):
-                r = self.fut.result()
-                if hasattr(r, "result"):   # the equal-length path hands back its vocoder job
-                    r = r.result()
-                return r[self.j]
+        def same_layout(a, c):
+            return all(a[k_].shape[1:] == c[k_].shape[1:] for k_ in keys)
+
+        def flow_worker():
+            """The flow thread: takes the oldest batch whose tokens it then waits for, adds the batches right behind it whose tokens are ALREADY
+            there (up to ``flow_merge``, same prompt lengths) and runs them as one pass — groups form across decode jobs when the flow side has
+            a backlog and never wait for tokens when it has none (the pipeline's fill)."""
+            while True:
+                with flow_cv:
+                    while not flow_q and not flow_state["closed"]:
+                        flow_cv.wait()
+                    if not flow_q:
+                        return
+                    grp = [flow_q.popleft()]
+                t0 = grp[0]
+                try:
+                    if flow_state["abort"]:
+                        raise RuntimeError("tts_batches closed before this batch was vocoded")
+                    t0["lf"].result()
+                    with flow_cv:
+                        while (len(grp) < fmerge and flow_q and flow_q[0]["lf"].done() and flow_q[0]["lf"].exception() is None
+                               and same_layout(t0["b"], flow_q[0]["b"])):
+                            grp.append(flow_q.popleft())
+                    res = flow_job([t["b"] for t in grp], [(t["lf"], t["idx"]) for t in grp], [t["ready"] for t in grp], flow_part)
+                except BaseException as e:
+                    for t in grp:
+                        t["fut"].set_exception(e)
+                    continue
+
+                def deliver(r, grp=grp):
+                    try:
+                        if hasattr(r, "result"):
+                            r = r.result()
+                        for t, x in zip(grp, r):
+                            t["fut"].set_result(x)
+                    except BaseException as e:
+                        for t in grp:
+                            if not t["fut"].done():
+                                t["fut"].set_exception(e)
+                if hasattr(res, "add_done_callback"):   # the equal-length overlap path hands back its vocoder job
+                    res.add_done_callback(deliver)
+                else:
+                    deliver(res)
 
         def collect(fut):
             wav, done = fut.result()
@@ -600,41 +634,49 @@ class CosyVoice2Model:
         n_jobs = 0
         with ThreadPoolExecutor(max_workers=n_llm) as llm_pool, ThreadPoolExecutor(max_workers=1) as flow_pool, \
                 ThreadPoolExecutor(max_workers=1) as hift_pool:
-            while nxt is not None or inflight:
-                # keep n_llm decode loops busy plus one job queued behind them
-                while nxt is not None and len(inflight) < (n_llm + 2) * merge:
-                    bs, rows = [], 0
-                    # the very first job stays a single batch: the pipeline fills sooner
+            flow_pool.submit(flow_worker)
+            try:
+                while nxt is not None or inflight:
+                    # keep n_llm decode loops busy plus one job queued behind them.  A job is admitted only when ALL its batches fit: a job cut short
+                    # by the in-flight cap (one batch in a 4-batch slot) occupies a decode loop for 70 % of a full job's time
                     job_batches = min(merge, ramp[n_jobs]) if n_jobs < len(ramp) else merge
-                    while nxt is not None and len(bs) < job_batches and rows + len(nxt["texts"]) <= self.llm.max_batch:
-                        rows += len(nxt["texts"])
-                        bs.append(nxt)
-                        nxt = draw()
-                    ready = torch.cuda.Event()
-                    with torch.cuda.stream(adm):
-                        for b in bs:
-                            if b.get("on_start") is not None:
-                                b["on_start"]()   # e.g. the conditioning broadcast: same order on every rank, never from worker threads
-                        ready.record(adm)
-                    n_jobs += 1
-                    with llm_state_lock:
-                        llm_state["running"] += 1
-                        llm_state["all_submitted"] = nxt is None
-                    lf = llm_pool.submit(llm_job, bs, ready, first)
-                    for g0 in range(0, len(bs), fmerge):   # flow groups: up to `flow_merge` consecutive batches of this decode job per pass
-                        idxs = list(range(g0, min(g0 + fmerge, len(bs))))
-                        last = nxt is None and idxs[-1] == len(bs) - 1
-                        gf = flow_pool.submit(flow_job, [bs[i] for i in idxs], lf, idxs, ready, flow_full if last else flow_part)
-                        for j, i in enumerate(idxs):
-                            inflight.append((bs[i], _Pick(gf, j)))
-                    first = False
-                b_done, fut = inflight.popleft()
-                try:
-                    wav = collect(fut)
-                finally:
-                    if b_done.get("on_done") is not None:
-                        b_done["on_done"]()   # every job of this batch (decode, flow, vocoder) has ended: its conditioning slot is free
-                yield wav
+                    while nxt is not None and (not inflight or len(inflight) + job_batches <= (n_llm + 2) * merge):
+                        bs, rows = [], 0
+                        while nxt is not None and len(bs) < job_batches and rows + len(nxt["texts"]) <= self.llm.max_batch:
+                            rows += len(nxt["texts"])
+                            bs.append(nxt)
+                            nxt = draw()
+                        ready = torch.cuda.Event()
+                        with torch.cuda.stream(adm):
+                            for b in bs:
+                                if b.get("on_start") is not None:
+                                    b["on_start"]()   # e.g. the conditioning broadcast: same order on every rank, never from worker threads
+                            ready.record(adm)
+                        n_jobs += 1
+                        with llm_state_lock:
+                            llm_state["running"] += 1
+                            llm_state["all_submitted"] = nxt is None
+                        lf = llm_pool.submit(llm_job, bs, ready, first)
+                        with flow_cv:
+                            for i, b in enumerate(bs):
+                                t = dict(b=b, lf=lf, idx=i, ready=ready, fut=Future())
+                                flow_q.append(t)
+                                inflight.append((b, t["fut"]))
+                            flow_cv.notify()
+                        first = False
+                        job_batches = min(merge, ramp[n_jobs]) if n_jobs < len(ramp) else merge
+                    b_done, fut = inflight.popleft()
+                    try:
+                        wav = collect(fut)
+                    finally:
+                        if b_done.get("on_done") is not None:
+                            b_done["on_done"]()   # every job of this batch (decode, flow, vocoder) has ended: its conditioning slot is free
+                    yield wav
+            finally:
+                with flow_cv:   # normal end: the queue is empty; a consumer that stopped early: the flow thread fails what is left instead of running it
+                    flow_state["closed"] = True
+                    flow_state["abort"] = bool(flow_q)
+                    flow_cv.notify()
         if est is not None:
             est.cu_budget = 0
 
