@@ -395,7 +395,9 @@ class CosyVoice2Model:
         launch (``ops.Graph.launch`` on a masked stream).  ``llm_loops`` (default ``self.llm_loops``) decode loops run
         concurrently on the decode CUs, each on its own batch with its own KV caches: a decode step is a chain of 124 short
         latency-bound kernels, and two interleaved chains deliver 1.5x the tokens per second of one.
-        ``llm_cu_slots=0`` keeps both stages on all CUs (two plain streams, one decode loop)."""
+        ``flow_merge`` > 1: the flow thread runs the oldest batch together with up to ``flow_merge`` - 1 batches right behind it whose tokens are
+        already there as ONE flow + vocoder pass (same mel per utterance: the flow is batch-invariant; rows come back to their batches in order).
+        ``llm_cu_slots=0`` keeps both stages on all CUs (two plain streams, one decode loop, no merging)."""
         k = self.llm_cu_slots if llm_cu_slots is None else llm_cu_slots
         n = self.llm_loops if llm_loops is None else llm_loops
         if k:
