@@ -227,7 +227,7 @@ def main():
     model.llm_merge = max(1, args.llm_merge)
     model.flow_merge = max(1, args.flow_merge)
     if model.flow_merge >= 3:
-        model.llm_ramp = (2, 2, 3)   # merged flow passes want their first groups sooner and larger (profiles/r03_flow_merge_sweeps.log)
+        model.llm_ramp = (2, 3, 3)   # merged flow passes want their first groups sooner and larger (profiles/r03_flow_merge_sweeps.log)
     # the fork drives CosyVoice2 modules through CosyVoiceModel wiring (full attention, model.py:50); the benchmark keeps
     # CosyVoice2Model's own chunk-50 encoder mask (model.py:314)
     flow.decoder.use_graph = True
