@@ -8,7 +8,9 @@ speech tokens = 10.0 s of 24 kHz audio; flow T = 1000 frames, 10 CFG Euler steps
 One "step" = the whole batch through the pipeline (prefill + 249 decode steps incl. on-device sampling, flow encoder +
 solver, HiFT, waveform D2H).  The K timed steps are software-pipelined (LLM decode of later steps overlaps flow + HiFT of
 step i, as the reference overlaps its LLM thread with flow/HiFT); all K steps' work, fill and drain included, lies inside
-the timed region.  Synthetic inputs + key-seeded random weights of the reference's architecture (no checkpoint exists
+the timed region; up to `--flow-merge` = 3 consecutive passes whose tokens are ready share ONE flow + HiFT launch sequence (same mel per utterance:
+the flow is batch-invariant, tests/test_model_gpu.py), and every graph capture / workspace allocation happens in set-up
+(`CosyVoice2Model.warm_pipeline_shapes`).  Synthetic inputs + key-seeded random weights of the reference's architecture (no checkpoint exists
 offline); inputs are resident in HBM before the timed region.
 
 N>1 (BASELINE configs[4]): one process per GPU (torchrun); a GLOBAL list of 8 x N utterances is sharded round-robin
