@@ -161,10 +161,13 @@ def test_v1_wiring_orchestrator_chunk_schedule(golden_dir):
 
 
 @pytest.mark.gpu
-def test_tts_batches_merged_loops_free_running():
+@pytest.mark.parametrize("fm", [1, 2])
+def test_tts_batches_merged_loops_free_running(fm):
     """Two batches per token loop without teacher forcing: every utterance ends at its own step, the merged job's tokens are
-    handed back per batch, flow + HiFT run per batch over ragged lengths."""
+    handed back per batch, flow + HiFT run per batch (fm = 1) or per merged group of two batches (fm = 2: the ragged flow pass over the
+    concatenated conditioning, waveforms split back per batch) over ragged lengths."""
     m, lc, fc, hc = _model()
+    m.flow_merge = fm
     B, nb = 2, 3
     shared = _inputs(lc, fc, seed=0)
     batches = []
