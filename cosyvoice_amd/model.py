@@ -648,6 +648,8 @@ class CosyVoice2Model:
                             rows += len(nxt["texts"])
                             bs.append(nxt)
                             nxt = draw()
+                        if not bs:
+                            raise ValueError(f"a batch of {len(nxt['texts'])} utterances exceeds the LLM's max_batch {self.llm.max_batch}")
                         ready = torch.cuda.Event()
                         with torch.cuda.stream(adm):
                             for b in bs:
